@@ -1,0 +1,146 @@
+/* lt_gpu.h -- C-ABI of the MI355X polygon rasterization library (libltgpu.so).
+ *
+ * Drop-in boundary for the polygon path of LightTrack / 3DGPL: the host-side engine
+ * keeps the reference's API (Engine.h, Graphics.h, Trans.h, Clipper.h, Colour.h) and
+ * forwards the data-parallel part to these entry points.  Plain pointers and sizes
+ * only; every function returns 0 on success or a negative LT_ERR_* code, and
+ * lt_last_error() gives the message (the reference itself has no error returns: it
+ * calls HW_error and exits, LightTrack.cpp:56-69; the host mirror maps a non-zero
+ * status to that behaviour).
+ *
+ * One context per GPU and per framebuffer; one host thread per context; all work of a
+ * context is issued on one HIP stream, in call order.  Draw order is call order, and
+ * inside one submit it is array order, as in M_render_polygon_object
+ * (EngPoly.cpp:518-523): where two fragments have equal depth the earlier polygon
+ * keeps the pixel (strict compare, GraphicsPoly.cpp:357).
+ *
+ * Flat scene layout (all int32, little endian):
+ *   verts      [nv][4]   X Y Z and an unused 4th lane (T_LNG_VECTOR, Trans.h:27)
+ *   polys      [np][4]   {colour 0x00RRGGBB, texture handle or -1, no_edges, first}
+ *                        (m_colour, m_texture, m_no_edges, m_vertices of struct
+ *                        M_polygon, Engine.h:209-230)
+ *   polyaux    [np][4]   {m_red, m_green, m_blue, m_type | m_log_texture_space_size<<8};
+ *                        needed for LT_FLAT; may be NULL otherwise
+ *   polyverts  [*][6]    M_polygon.m_vertices records [Idx R G B Tx Ty]
+ *                        (M_LNG_POLYGON_VERTEX, Engine.h:204-207); polygon i owns records
+ *                        first .. first+no_edges (the closing vertex is stored)
+ *   screen tuples [*][dim]  X Y Z' [R G B [Tx Ty]] as T_perspective leaves them
+ *                        (dim 3, 6 or 8: G_LNG_FLAT/SHADED/TEXTURED, Graphics.h:54-58),
+ *                        R G B Tx Ty in 16.16 fixed point
+ *   framebuffer          colour int32[H][W] 0x00RRGGBB and depth int32[H][W], row stride W
+ *                        (G_c_buffer / G_z_buffer, GraphicsBase.cpp:35-42)
+ */
+#ifndef LT_GPU_H
+#define LT_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lt_ctx lt_ctx;
+
+/* rendering types: M_FLAT / M_SHADED / M_TEXTURED, Engine.h:81-83 */
+#define LT_FLAT      2
+#define LT_SHADED    4
+#define LT_TEXTURED  8
+
+#define LT_OK                 0
+#define LT_ERR_ARG           -1   /* bad argument */
+#define LT_ERR_HIP           -2   /* a HIP call failed */
+#define LT_ERR_OVERFLOW      -3   /* a clipped polygon needs more than 16 tuples (G_MAX_POLYGON_VERTICES, Graphics.h:37) */
+#define LT_ERR_CAPACITY      -4   /* tile list capacity exceeded: raise it with lt_set_list_capacity */
+#define LT_ERR_UNSUPPORTED   -5   /* input needs a part of the reference this library does not cover (see message) */
+
+#define LT_MAX_TEXTURES      64
+#define LT_MAX_SCREEN     16384   /* width and height limit */
+
+/* counters of the work done since the last lt_reset_counters */
+typedef struct lt_counters {
+    uint64_t fragments;        /* Z tests = pixels of all spans of all drawn polygons (the inner loop of GraphicsPoly.cpp:355-381) */
+    uint64_t polys_in;         /* polygons submitted */
+    uint64_t polys_drawn;      /* polygons that reached the fill (passed volume clip and back-face cull) */
+    uint64_t tile_refs;        /* (polygon, screen tile) pairs binned */
+    uint64_t overflow_polys;   /* polygons dropped for LT_ERR_OVERFLOW */
+    uint64_t order_dependent_rows; /* textured rows whose light varies along the span (GraphicsPoly.cpp:485-493) */
+    uint64_t unsupported_polys;
+    uint64_t list_overflow;    /* tile references that did not fit */
+} lt_counters;
+
+/* --- context ------------------------------------------------------------------ */
+
+/* Replaces G_init_graphics (GraphicsBase.cpp:70-89): allocates the colour and depth
+ * buffers in HBM for a width x height screen (a run-time value here; the reference
+ * fixes it at compile time, LightTrack.h:44-45). */
+int lt_ctx_create(int device, int width, int height, lt_ctx **out);
+int lt_ctx_destroy(lt_ctx *ctx);
+const char *lt_last_error(lt_ctx *ctx);          /* ctx may be NULL: last creation error */
+
+/* Issue the context's work on an existing hipStream_t (NULL = the default stream). */
+int lt_set_stream(lt_ctx *ctx, void *hip_stream);
+/* Capacity, in (polygon, tile) references, of the per-submit tile lists.  0 = default
+ * (64 per polygon, at least 1M). */
+int lt_set_list_capacity(lt_ctx *ctx, uint64_t refs);
+
+/* --- framebuffer --------------------------------------------------------------- */
+
+/* G_clear (GraphicsBase.cpp:99-111) with the lit colour already computed
+ * (CL_light(colour,r,g,b), Colour.cpp:93-102): colour buffer <- colour, depth <- INT_MAX.
+ * The fill is deferred into the first rasterization that follows. */
+int lt_clear(lt_ctx *ctx, int32_t lit_colour);
+/* Blocks until all submitted work is done and reports any error it raised.  This is
+ * the point where the reference's HW_blit would read the frame (LightTrack.cpp:284-298). */
+int lt_flush(lt_ctx *ctx);
+/* lt_flush, then copy the frame to host memory (either pointer may be NULL). */
+int lt_readback(lt_ctx *ctx, int32_t *colour, int32_t *depth);
+/* Device addresses of the frame, valid until lt_ctx_destroy; contents are current after lt_flush. */
+int lt_framebuffer(lt_ctx *ctx, int32_t **d_colour, int32_t **d_depth);
+int lt_get_counters(lt_ctx *ctx, lt_counters *out);   /* implies lt_flush */
+int lt_reset_counters(lt_ctx *ctx);
+
+/* m_texture_bytes / m_log_texture_size of struct M_texture (Engine.h:148-152): copies a
+ * 2^log_size square of int32 texels to HBM under `handle` (0 .. LT_MAX_TEXTURES-1). */
+int lt_texture_upload(lt_ctx *ctx, int handle, const int32_t *texels, int log_size);
+
+/* --- the path ------------------------------------------------------------------- */
+
+/* T_cancatinated_rotation (TransBs.cpp:373-393) with the matrix as an argument:
+ * m = {cx1 cy1 cz1 tx, cx2 cy2 cz2 ty, cx3 cy3 cz3 tz} (T_c* / T_t* of
+ * T_cancatinate_self_world, TransBs.cpp:325-361).  d_from and d_to are DEVICE
+ * pointers to int32[n][4]; the 4th lane of d_to is left untouched. */
+int lt_transform(lt_ctx *ctx, const int32_t m[12], const int32_t *d_from, int32_t *d_to, int n);
+
+/* M_render_polygon_object (EngPoly.cpp:499-525) for one object of np polygons, after
+ * the host has built the matrix (T_set_self_rotation + T_cancatinate_self_world):
+ * transform, then per polygon what M_render_polygon does (EngBase.cpp:379-552) --
+ * tuples, view-volume test, near-plane clip, perspective, back-face cull, screen
+ * clip, edge scan, span fill with depth test.  render_type is what M_init_rendering
+ * set; log_focus what M_set_camera set; force_linear is M_force_linear_tmapping.
+ * max_edges bounds no_edges over the batch (0 = 15).  Pointers are HOST memory; the
+ * call copies them to the GPU and returns after enqueueing. */
+int lt_submit_object(lt_ctx *ctx, const int32_t m[12],
+                     const int32_t *verts, int nv,
+                     const int32_t *polys, const int32_t *polyaux, int np,
+                     const int32_t *polyverts, int npv,
+                     int render_type, int log_focus, int force_linear, int max_edges);
+/* The same with every array already in DEVICE memory (nothing is copied). */
+int lt_submit_object_dev(lt_ctx *ctx, const int32_t m[12],
+                         const int32_t *d_verts, int nv,
+                         const int32_t *d_polys, const int32_t *d_polyaux, int np,
+                         const int32_t *d_polyverts, int npv,
+                         int render_type, int log_focus, int force_linear, int max_edges);
+
+/* G_flat_polygon / G_shaded_polygon / G_lin_textured_polygon (GraphicsPoly.cpp:230-502)
+ * for n already-projected closed polygons, in array order.  kind = LT_FLAT (dim 3),
+ * LT_SHADED (dim 6) or LT_TEXTURED (dim 8).  desc[i] = {first tuple, length (edges),
+ * colour, texture handle}: for LT_FLAT colour is the lit colour CL_light(colour,r,g,b),
+ * for LT_SHADED the base colour.  Polygon i reads tuples first .. first+length.
+ * HOST pointers. */
+int lt_submit_screen_polys(lt_ctx *ctx, int kind, const int32_t *tuples, int ntuples,
+                           const int32_t *desc, int n, int max_edges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,760 @@
+/* CPU restatement of the reference's polygon rasterization path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the checker for the HIP library: only the
+ * tests, the smoke check and the benchmark's cpu_baseline leg may load it; the product
+ * library never links or calls it.
+ *
+ * Parity is pinned: every function here is checked against the reference's own code
+ * (compiled from /root/reference by oracle/build_ref.sh) by tests/test_oracle_vs_ref.py
+ * and against the committed vectors under tests/golden/ that the same reference build
+ * produced.
+ *
+ * It is a plain sequential restatement, in the same order of operations as the
+ * reference, with the screen size as a run-time parameter (the reference fixes it at
+ * compile time, LightTrack.h:44-45) and with 32-bit wrap-around made explicit.  All
+ * arithmetic is integer; ">>" is an arithmetic shift, "/" truncates toward zero, and
+ * add, subtract, multiply and "<<" wrap modulo 2^32 (the reference build this is pinned
+ * against is compiled -fwrapv on an LP64 target, so its "long" is 64 bits wide).
+ *
+ * Build configuration restated: _RGB_ _32BPP_ _FIXED_ _Z_BUFFER_ _MONO_
+ * (LightTrack.dsp:46).  Build: gcc -O2 -fwrapv -shared -fPIC (see __graft_entry__.build).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <math.h>
+
+#define LTO_MAX_DIM       8      /* C_MAX_DIMENSIONS, Clipper.h:17 */
+#define LTO_MAX_TUPLES   16      /* G_MAX_POLYGON_VERTICES, Graphics.h:37 */
+#define LTO_WORK_TUPLES  64      /* working room; more than 16 sets the overflow flag */
+#define LTO_GP           16      /* G_P, Graphics.h:39 */
+#define LTO_TP           15      /* T_P, Trans.h:31 */
+#define LTO_Z_MIN        10      /* C_Z_CLIPPING_MIN, Clipper.h:19 */
+#define LTO_Z_CONST (-0x7ffff)   /* T_ONE_OVER_Z_CONST, Trans.h:30 */
+#define LTO_Z_SWITCH   1024      /* G_Z_MAPPING_SWITCH, Graphics.h:38 */
+#define LTO_LINEAR       32      /* G_LINEAR, GraphicsPoly.cpp:40 */
+#define LTO_M_WIRE        1      /* Engine.h:80-83 */
+#define LTO_M_FLAT        2
+#define LTO_M_SHADED      4
+#define LTO_M_TEXTURED    8
+#define LTO_M_QUAD_XY     4      /* Engine.h:193-195 */
+#define LTO_M_QUAD     0x0c
+#define LTO_MAX_TEXTURES 64
+
+typedef int32_t i32;
+typedef uint32_t u32;
+typedef int64_t i64;
+
+static inline i32 wadd(i32 a,i32 b){ return (i32)((u32)a+(u32)b); }
+static inline i32 wsub(i32 a,i32 b){ return (i32)((u32)a-(u32)b); }
+static inline i32 wmul(i32 a,i32 b){ return (i32)((u32)a*(u32)b); }
+static inline i32 wshl(i32 a,int s){ return (i32)((u32)a<<s); }
+/* truncating division that cannot trap on INT_MIN/-1 (wraps like the hardware the
+ * reference ran on would not: that case never occurs with divisors >= 1) */
+static inline i32 tdiv(i32 a,i32 b){ return (i32)((i64)a/(i64)b); }
+
+typedef struct lto_ctx {
+    int w,h;
+    i32 *cbuf,*zbuf;
+    i32 *xs,*xe;                 /* G_x_start / G_x_end, GraphicsPoly.cpp:44-45 */
+    i32 *vs[6],*ve[6];           /* G_0..5_start / _end, GraphicsPoly.cpp:46-57 */
+    int miny,maxy;
+    int log_focus;               /* M_camera_log_focus */
+    int fast_reset;              /* 1: reset only the rows a polygon touched */
+    int touched_lo,touched_hi;
+    const i32 *tex[LTO_MAX_TEXTURES];
+    int tex_log[LTO_MAX_TEXTURES];
+    uint64_t fragments,passes,polys_in,polys_drawn,overflow,unsupported;
+} lto_ctx;
+
+/* ------------------------------------------------------------------ colour */
+
+/* CL_light, Colour.cpp:93-102 with the table of Colour.cpp:44-56 evaluated
+ * arithmetically: CL_div[c][l] = (c*l)/255, light clamped from above only
+ * (Colour.h:135). */
+i32 lto_cl_light(i32 colour,i32 r,i32 g,i32 b)
+{
+    i32 cr=(colour>>16)&0xff, cg=(colour>>8)&0xff, cb=colour&0xff;
+    if(r>255) r=255;
+    if(g>255) g=255;
+    if(b>255) b=255;
+    return (((cr*r)/255)<<16) | (((cg*g)/255)<<8) | ((cb*b)/255);
+}
+
+/* CL_colour, Colour.cpp:67-76 */
+i32 lto_cl_colour(i32 r,i32 g,i32 b)
+{
+    if(r>255) r=255;
+    if(g>255) g=255;
+    if(b>255) b=255;
+    return (r<<16)|(g<<8)|b;
+}
+
+/* ------------------------------------------------------------------ context */
+
+lto_ctx *lto_create(int w,int h)
+{
+    lto_ctx *c=(lto_ctx*)calloc(1,sizeof(lto_ctx));
+    int j;
+    if(!c) return NULL;
+    c->w=w; c->h=h;
+    c->cbuf=(i32*)malloc(sizeof(i32)*(size_t)w*h);     /* G_init_graphics, GraphicsBase.cpp:70-89 */
+    c->zbuf=(i32*)malloc(sizeof(i32)*(size_t)w*h);
+    c->xs=(i32*)malloc(sizeof(i32)*h);
+    c->xe=(i32*)malloc(sizeof(i32)*h);
+    for(j=0;j<6;j++){ c->vs[j]=(i32*)calloc(h,sizeof(i32)); c->ve[j]=(i32*)calloc(h,sizeof(i32)); }
+    for(j=0;j<h;j++){ c->xs[j]=INT_MAX; c->xe[j]=INT_MIN; }
+    c->touched_lo=0; c->touched_hi=-1;
+    return c;
+}
+
+void lto_destroy(lto_ctx *c)
+{
+    int j;
+    if(!c) return;
+    free(c->cbuf); free(c->zbuf); free(c->xs); free(c->xe);
+    for(j=0;j<6;j++){ free(c->vs[j]); free(c->ve[j]); }
+    free(c);
+}
+
+i32 *lto_cbuf(lto_ctx *c){ return c->cbuf; }
+i32 *lto_zbuf(lto_ctx *c){ return c->zbuf; }
+void lto_set_fast_reset(lto_ctx *c,int on){ c->fast_reset=on; }
+void lto_set_texture(lto_ctx *c,int handle,const i32 *texels,int log_size)
+{ c->tex[handle]=texels; c->tex_log[handle]=log_size; }
+
+void lto_counters(lto_ctx *c,uint64_t *out)
+{
+    out[0]=c->fragments; out[1]=c->passes; out[2]=c->polys_in;
+    out[3]=c->polys_drawn; out[4]=c->overflow; out[5]=c->unsupported;
+}
+void lto_reset_counters(lto_ctx *c)
+{ c->fragments=c->passes=c->polys_in=c->polys_drawn=c->overflow=c->unsupported=0; }
+
+/* G_clear, GraphicsBase.cpp:99-111 */
+void lto_clear(lto_ctx *c,i32 colour,i32 r,i32 g,i32 b)
+{
+    size_t n=(size_t)c->w*c->h,i;
+    i32 v=lto_cl_light(colour,r,g,b);
+    for(i=0;i<n;i++){ c->cbuf[i]=v; c->zbuf[i]=INT_MAX; }
+}
+
+/* ------------------------------------------------------------------ transforms */
+
+/* T_init_math: variant 0 follows Trans.cpp:62-77 (scale, then truncate), variant 1
+ * follows TransBs.cpp:63-78 (truncate, then scale). */
+void lto_trig_tables(int variant,i32 *s,i32 *co)
+{
+    int i;
+    for(i=0;i<256;i++)
+    {
+        if(variant==0){ s[i]=(i32)(sin(i/40.7436642)*(1<<LTO_TP)); co[i]=(i32)(cos(i/40.7436642)*(1<<LTO_TP)); }
+        else { s[i]=((int)sin(i/40.7436642))*(1<<LTO_TP); co[i]=((int)cos(i/40.7436642))*(1<<LTO_TP); }
+    }
+}
+
+#define FX(a,b) (wmul((a),(b))>>LTO_TP)
+
+/* T_set_self_rotation, TransBs.cpp:144-183 -> s[9] = sx1 sy1 sz1 sx2 sy2 sz2 sx3 sy3 sz3 */
+static void self_rotation(const i32 *S,const i32 *C,int alp,int bet,int gam,i32 *s)
+{
+    i32 ca=C[alp&255],sa=S[alp&255],cb=C[bet&255],sb=S[bet&255],cg=C[gam&255],sg=S[gam&255];
+    s[0]=wsub(FX(ca,cg),FX(sa,FX(sb,sg)));
+    s[1]=wadd(FX(sa,cg),FX(ca,FX(sb,sg)));
+    s[2]=FX(cb,sg);
+    s[3]=-FX(sa,cb);
+    s[4]=FX(ca,cb);
+    s[5]=-sb;
+    s[6]=wsub(-FX(ca,sg),FX(sa,FX(sb,cg)));
+    s[7]=wsub(FX(ca,FX(sb,cg)),FX(sa,sg));
+    s[8]=FX(cb,cg);
+}
+
+/* T_set_world_rotation, TransBs.cpp:239-278 -> w[9] = wx1 wy1 wz1 wx2 wy2 wz2 wx3 wy3 wz3 */
+static void world_rotation(const i32 *S,const i32 *C,int alp,int bet,int gam,i32 *w)
+{
+    i32 ca=C[alp&255],sa=S[alp&255],cb=C[bet&255],sb=S[bet&255],cg=C[gam&255],sg=S[gam&255];
+    w[0]=wadd(FX(sg,FX(sb,sa)),FX(cg,ca));
+    w[1]=FX(cb,sa);
+    w[2]=wsub(FX(sg,ca),FX(cg,FX(sb,sa)));
+    w[3]=wsub(FX(sg,FX(sb,ca)),FX(cg,sa));
+    w[4]=FX(cb,ca);
+    w[5]=wsub(-FX(cg,FX(sb,ca)),FX(sg,sa));
+    w[6]=-FX(sg,cb);
+    w[7]=sb;
+    w[8]=FX(cg,cb);
+}
+
+/* M_set_camera (EngBase.cpp:201-213) + T_set_self_rotation +
+ * T_cancatinate_self_world (TransBs.cpp:325-361) as M_render_polygon_object
+ * calls them (EngPoly.cpp:510-511).
+ * m12 rows: {cx1 cy1 cz1 tx, cx2 cy2 cz2 ty, cx3 cy3 cz3 tz}. */
+void lto_make_matrix(int variant,int cam_alp,int cam_bet,int cam_gam,
+                     i32 cam_x,i32 cam_y,i32 cam_z,
+                     int alp,int bet,int gam,i32 x,i32 y,i32 z,i32 *m)
+{
+    i32 S[256],C[256],s[9],w[9],ax,ay,az;
+    int r;
+    lto_trig_tables(variant,S,C);
+    world_rotation(S,C,(unsigned char)(256-cam_alp),(unsigned char)(256-cam_bet),
+                   (unsigned char)(256-cam_gam),w);
+    self_rotation(S,C,(unsigned char)alp,(unsigned char)bet,(unsigned char)gam,s);
+    ax=wadd(x,-cam_x); ay=wadd(y,-cam_y); az=wadd(z,-cam_z);
+    for(r=0;r<3;r++)
+    {   /* column r of W is (w[3r], w[3r+1], w[3r+2]) = (wx,wy,wz)_{r+1} */
+        i32 wx=w[3*r],wy=w[3*r+1],wz=w[3*r+2];
+        m[4*r+0]=wadd(wadd(FX(s[0],wx),FX(s[3],wy)),FX(s[6],wz));   /* cx: sx1 sx2 sx3 */
+        m[4*r+1]=wadd(wadd(FX(s[1],wx),FX(s[4],wy)),FX(s[7],wz));   /* cy: sy1 sy2 sy3 */
+        m[4*r+2]=wadd(wadd(FX(s[2],wx),FX(s[5],wy)),FX(s[8],wz));   /* cz: sz1 sz2 sz3 */
+        m[4*r+3]=wadd(wadd(FX(ax,wx),FX(ay,wy)),FX(az,wz));
+    }
+}
+
+/* T_cancatinated_rotation, TransBs.cpp:373-393; the 4th element is left alone. */
+void lto_transform(const i32 *m,const i32 *from,i32 *to,int n)
+{
+    int i,r;
+    for(i=0;i<n;i++,from+=4,to+=4)
+    {
+        i32 x=from[0],y=from[1],z=from[2];
+        for(r=0;r<3;r++)
+            to[r]=wadd(wadd(wadd(FX(m[4*r],x),FX(m[4*r+1],y)),FX(m[4*r+2],z)),m[4*r+3]);
+    }
+}
+
+/* T_perspective, TransBs.cpp:416-434 */
+void lto_perspective(const lto_ctx *c,const i32 *from,i32 *to,int dim,int len,int log_focus)
+{
+    int i,j;
+    for(i=0;i<len;i++,from+=dim,to+=dim)
+    {
+        i64 z=from[2];
+        to[0]=wadd((i32)(((i64)from[0]*((i64)1<<log_focus))/z),c->w/2);
+        to[1]=wadd((i32)(((i64)from[1]*((i64)1<<log_focus))/z),c->h/2);
+        to[2]=(i32)((i64)LTO_Z_CONST/z);
+        for(j=3;j<dim;j++) to[j]=from[j];
+    }
+}
+
+/* T_normal_z_negative, TransLn.cpp:218-223 */
+int lto_normal_z_negative(const i32 *a,const i32 *b,const i32 *c)
+{
+    return ((i64)wsub(b[0],a[0])*(i64)wsub(c[1],a[1])-
+            (i64)wsub(b[1],a[1])*(i64)wsub(c[0],a[0]))<0;
+}
+
+/* ------------------------------------------------------------------ clipping */
+
+/* C_volume_clipping, Clipp3D.cpp:46-58 */
+int lto_volume_clipping(const i32 *mn,const i32 *mx)
+{
+    if((mx[2]<mn[0])||(mx[2]<mn[1])||(mx[2]<-mx[0])||(mx[2]<-mx[1])||(mx[2]<=LTO_Z_MIN)) return 0;
+    return (mn[2]<LTO_Z_MIN)?-1:1;
+}
+
+static void midpoint(i32 *m,const i32 *l,const i32 *r,int dim)
+{ int i; for(i=0;i<dim;i++) m[i]=wadd(l[i],r[i])>>1; }
+
+/* One routine for C_line_x_clipping / C_line_y_clipping (Clipp2D.cpp:94-228; both
+ * sides, axis 0 or 1) and C_line_z_clipping (Clipp3D.cpp:70-110; near side only,
+ * axis 2).  Binary search on every dimension until the clipped coordinate equals the
+ * bound.  *first_moved restates C_2D_clipping / C_3D_clipping. */
+static int clip_line(const i32 *v1,const i32 *v2,int dim,int axis,i32 bmin,i32 bmax,
+                     int both,i32 *o1,i32 *o2,int *first_moved)
+{
+    i32 lo[LTO_MAX_DIM],hi[LTO_MAX_DIM],l[LTO_MAX_DIM],r[LTO_MAX_DIM],m[LTO_MAX_DIM];
+    int swap,whereto;
+    *first_moved=0;
+    if(v1[axis]<v2[axis]){ swap=0; memcpy(lo,v1,dim*4); memcpy(hi,v2,dim*4); }
+    else                 { swap=1; memcpy(lo,v2,dim*4); memcpy(hi,v1,dim*4); }
+    if(both){ if((lo[axis]>=bmax)||(hi[axis]<=bmin)) return 0; }
+    else    { if(hi[axis]<=bmin) return 0; }
+
+    if(lo[axis]<=bmin)
+    {
+        memcpy(m,lo,dim*4); memcpy(r,hi,dim*4);
+        whereto=1;
+        while(m[axis]!=bmin)
+        {
+            if(whereto) memcpy(l,m,dim*4); else memcpy(r,m,dim*4);
+            midpoint(m,l,r,dim);
+            whereto=m[axis]<bmin;
+        }
+        memcpy(lo,m,dim*4);
+        *first_moved=swap^1;
+    }
+    if(both&&(hi[axis]>=bmax))
+    {
+        memcpy(l,lo,dim*4); memcpy(m,hi,dim*4);
+        whereto=0;
+        while(m[axis]!=bmax)
+        {
+            if(whereto) memcpy(l,m,dim*4); else memcpy(r,m,dim*4);
+            midpoint(m,l,r,dim);
+            whereto=m[axis]<bmax;
+        }
+        memcpy(hi,m,dim*4);
+        *first_moved|=swap&1;
+    }
+    if(swap){ memcpy(o1,hi,dim*4); memcpy(o2,lo,dim*4); }
+    else    { memcpy(o1,lo,dim*4); memcpy(o2,hi,dim*4); }
+    return 1;
+}
+
+int lto_line_clipping(const lto_ctx *c,int axis,const i32 *v1,const i32 *v2,int dim,
+                      i32 *o1,i32 *o2,int *first_moved)
+{
+    if(axis==0) return clip_line(v1,v2,dim,0,0,c->w-1,1,o1,o2,first_moved);
+    if(axis==1) return clip_line(v1,v2,dim,1,0,c->h-1,1,o1,o2,first_moved);
+    return clip_line(v1,v2,dim,2,LTO_Z_MIN,0,0,o1,o2,first_moved);
+}
+
+/* C_polygon_z_clipping (Clipp3D.cpp:129-159) and C_polygon_x_clipping
+ * (Clipp2D.cpp:247-275): `to` must hold LTO_WORK_TUPLES tuples; returns the new
+ * edge count (may exceed what the reference's arrays could hold: caller checks). */
+static int clip_polygon(const lto_ctx *c,int axis,const i32 *from,i32 *to,int dim,int len)
+{
+    int i,n=0,moved;
+    i32 a[LTO_MAX_DIM],b[LTO_MAX_DIM];
+    for(i=0;i<len;i++)
+    {
+        if(lto_line_clipping(c,axis,from+i*dim,from+(i+1)*dim,dim,a,b,&moved))
+        {
+            if(n+3>LTO_WORK_TUPLES) return LTO_WORK_TUPLES;     /* out of working room */
+            if(moved){ memcpy(to+n*dim,a,dim*4); n++; memcpy(to+n*dim,b,dim*4); n++; }
+            else     { memcpy(to+n*dim,b,dim*4); n++; }
+        }
+    }
+    if(n>0) memcpy(to+n*dim,to,dim*4);
+    return n;
+}
+
+int lto_polygon_z_clipping(const lto_ctx *c,const i32 *from,i32 *to,int dim,int len)
+{ return clip_polygon(c,2,from,to,dim,len); }
+int lto_polygon_x_clipping(const lto_ctx *c,const i32 *from,i32 *to,int dim,int len)
+{ return clip_polygon(c,0,from,to,dim,len); }
+
+/* ------------------------------------------------------------------ edge scan */
+
+/* GI_boarder_array_init, GraphicsPoly.cpp:209-216 */
+static void border_init(lto_ctx *c)
+{
+    int y;
+    c->miny=INT_MAX; c->maxy=INT_MIN;
+    if(c->fast_reset)
+    {
+        for(y=c->touched_lo;y<=c->touched_hi;y++){ c->xs[y]=INT_MAX; c->xe[y]=INT_MIN; }
+        c->touched_lo=c->h; c->touched_hi=-1;
+    }
+    else
+        for(y=0;y<c->h;y++){ c->xs[y]=INT_MAX; c->xe[y]=INT_MIN; }
+}
+
+/* GI_scan, GraphicsPoly.cpp:124-200.  dim = number of values per tuple that are
+ * interpolated (incl. X Y), skip = tuple stride. */
+static void scan_edge(lto_ctx *c,const i32 *edge,int dim,int skip)
+{
+    i32 a[LTO_MAX_DIM],b[LTO_MAX_DIM],cur[6],inc[6];
+    int moved,i,j,nv=dim-2;
+    i32 x,y,dx,dy,long_d,short_d,d,add_dh,add_dl,ixh,iyh,ixl,iyl;
+
+    if(!clip_line(edge,edge+skip,dim,1,0,c->h-1,1,a,b,&moved)) return;
+
+    x=a[0]; y=a[1]; dx=b[0]; dy=b[1];
+    if(y<c->miny) c->miny=y;
+    if(y>c->maxy) c->maxy=y;
+    if(dy<c->miny) c->miny=dy;
+    if(dy>c->maxy) c->maxy=dy;
+    if(c->fast_reset)
+    {
+        i32 lo=y<dy?y:dy,hi=y<dy?dy:y;
+        if(lo<c->touched_lo) c->touched_lo=lo;
+        if(hi>c->touched_hi) c->touched_hi=hi;
+    }
+    dx-=x; dy-=y;
+    if(dx<0){ dx=-dx; ixh=-1; ixl=-1; } else { ixh=1; ixl=1; }
+    if(dy<0){ dy=-dy; iyh=-1; iyl=-1; } else { iyh=1; iyl=1; }
+    if(dx>dy){ long_d=dx; short_d=dy; iyl=0; } else { long_d=dy; short_d=dx; ixl=0; }
+    d=2*short_d-long_d; add_dl=2*short_d; add_dh=2*(short_d-long_d);
+
+    for(j=0;j<6;j++) inc[j]=0;                      /* unset in the reference when long_d==0; never used then */
+    cur[0]=wshl(a[2],LTO_GP);
+    if(long_d>0) inc[0]=tdiv(wshl(wsub(b[2],a[2]),LTO_GP),long_d);
+    for(j=1;j<nv;j++)
+    {
+        cur[j]=a[2+j];
+        if(long_d>0) inc[j]=tdiv(wsub(b[2+j],a[2+j]),long_d);
+    }
+    for(i=0;i<=long_d;i++)
+    {
+        if(x<c->xs[y]){ c->xs[y]=x; for(j=0;j<nv;j++) c->vs[j][y]=cur[j]; }
+        if(c->xe[y]<x){ c->xe[y]=x; for(j=0;j<nv;j++) c->ve[j][y]=cur[j]; }
+        if(d>=0){ x+=ixh; y+=iyh; d+=add_dh; } else { x+=ixl; y+=iyl; d+=add_dl; }
+        for(j=0;j<nv;j++) cur[j]=wadd(cur[j],inc[j]);
+    }
+}
+
+/* x clip + scan of all edges; returns 0 if the clipped polygon would not fit the
+ * reference's 16-tuple arrays (the reference would overrun its stack there). */
+static int scan_polygon(lto_ctx *c,const i32 *tuples,int length,int dim,int scan_dim)
+{
+    i32 clipped[LTO_WORK_TUPLES*LTO_MAX_DIM+LTO_MAX_DIM];
+    int n,i;
+    border_init(c);
+    n=clip_polygon(c,0,tuples,clipped,dim,length);
+    if(n+1>LTO_MAX_TUPLES){ c->overflow++; c->miny=INT_MAX; c->maxy=INT_MIN; return 0; }
+    for(i=0;i<n;i++) scan_edge(c,clipped+i*dim,scan_dim,dim);
+    return 1;
+}
+
+void lto_scan_polygon(lto_ctx *c,const i32 *tuples,int length,int dim,int *miny,int *maxy,
+                      i32 *xs,i32 *xe,i32 *vstart,i32 *vend)
+{
+    int y,j;
+    scan_polygon(c,tuples,length,dim,dim);
+    *miny=c->miny; *maxy=c->maxy;
+    for(y=0;y<c->h;y++)
+    {
+        xs[y]=c->xs[y]; xe[y]=c->xe[y];
+        for(j=0;j<dim-2;j++)
+        {
+            vstart[y*6+j]=(xs[y]!=INT_MAX)?c->vs[j][y]:0;
+            vend[y*6+j]=(xe[y]!=INT_MIN)?c->ve[j][y]:0;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ fills */
+
+/* G_flat_polygon, GraphicsPoly.cpp:230-291 */
+void lto_flat_polygon(lto_ctx *c,const i32 *tuples,int length,i32 colour,i32 r,i32 g,i32 b)
+{
+    i32 hw=lto_cl_light(colour,r,g,b);
+    int y;
+    if(!scan_polygon(c,tuples,length,3,3)) return;
+    if(!(c->miny<c->maxy)) return;
+    for(y=c->miny;y<c->maxy;y++)
+    {
+        i32 beg=c->xs[y],end=c->xe[y],span=wsub(end,beg),cz,iz=0,x;
+        size_t pos=(size_t)y*c->w;
+        if(beg==INT_MAX) continue;                   /* row never touched: the reference's loop body does not run */
+        cz=c->vs[0][y];
+        if(span!=0) iz=tdiv(wsub(c->ve[0][y],cz),span);
+        for(x=beg;x<=end;x++)
+        {
+            c->fragments++;
+            if(c->zbuf[pos+x]>(cz>>LTO_GP)){ c->zbuf[pos+x]=cz>>LTO_GP; c->cbuf[pos+x]=hw; c->passes++; }
+            cz=wadd(cz,iz);
+        }
+    }
+}
+
+/* G_shaded_polygon, GraphicsPoly.cpp:300-384 */
+void lto_shaded_polygon(lto_ctx *c,const i32 *tuples,int length,i32 colour)
+{
+    int y;
+    if(!scan_polygon(c,tuples,length,6,6)) return;
+    if(!(c->miny<c->maxy)) return;
+    for(y=c->miny;y<c->maxy;y++)
+    {
+        i32 beg=c->xs[y],end=c->xe[y],span=wsub(end,beg),x;
+        i32 cz,cr,cg,cb,iz,ir,ig,ib;
+        size_t pos=(size_t)y*c->w;
+        if(beg==INT_MAX) continue;                   /* row never touched: the reference's loop body does not run */
+        if(span==0) span=1;
+        cr=c->vs[1][y]; ir=tdiv(wsub(c->ve[1][y],cr),span);
+        cg=c->vs[2][y]; ig=tdiv(wsub(c->ve[2][y],cg),span);
+        cb=c->vs[3][y]; ib=tdiv(wsub(c->ve[3][y],cb),span);
+        cz=c->vs[0][y]; iz=tdiv(wsub(c->ve[0][y],cz),span);
+        for(x=beg;x<=end;x++)
+        {
+            c->fragments++;
+            if(c->zbuf[pos+x]>(cz>>LTO_GP))
+            {
+                c->zbuf[pos+x]=cz>>LTO_GP;
+                c->cbuf[pos+x]=lto_cl_light(colour,cr>>LTO_GP,cg>>LTO_GP,cb>>LTO_GP);
+                c->passes++;
+            }
+            cr=wadd(cr,ir); cg=wadd(cg,ig); cb=wadd(cb,ib); cz=wadd(cz,iz);
+        }
+    }
+}
+
+/* G_lin_textured_polygon, GraphicsPoly.cpp:398-502.  The light accumulators advance
+ * only when the depth test passes (GraphicsPoly.cpp:485-493). */
+void lto_lin_textured_polygon(lto_ctx *c,const i32 *tuples,int length,const i32 *texture,int log_size)
+{
+    i32 mask=wsub(wshl(1,log_size+LTO_GP),1);
+    int y;
+    if(!scan_polygon(c,tuples,length,8,8)) return;
+    if(!(c->miny<c->maxy)) return;
+    for(y=c->miny;y<c->maxy;y++)
+    {
+        i32 beg=c->xs[y],end=c->xe[y],span=wsub(end,beg),x;
+        i32 cz,cr,cg,cb,tx,ty,iz,ir,ig,ib,itx,ity;
+        size_t pos=(size_t)y*c->w;
+        if(beg==INT_MAX) continue;
+        if(span==0) span=1;
+        tx=c->vs[4][y]; itx=tdiv(wsub(c->ve[4][y],tx),span);
+        ty=c->vs[5][y]; ity=tdiv(wsub(c->ve[5][y],ty),span);
+        cr=c->vs[1][y]; ir=tdiv(wsub(c->ve[1][y],cr),span);
+        cg=c->vs[2][y]; ig=tdiv(wsub(c->ve[2][y],cg),span);
+        cb=c->vs[3][y]; ib=tdiv(wsub(c->ve[3][y],cb),span);
+        cz=c->vs[0][y]; iz=tdiv(wsub(c->ve[0][y],cz),span);
+        for(x=beg;x<=end;x++)
+        {
+            tx&=mask; ty&=mask;
+            c->fragments++;
+            if(c->zbuf[pos+x]>(cz>>LTO_GP))
+            {
+                c->zbuf[pos+x]=cz>>LTO_GP;
+                c->cbuf[pos+x]=lto_cl_light(texture[((ty>>LTO_GP)<<log_size)+(tx>>LTO_GP)],
+                                            cr>>LTO_GP,cg>>LTO_GP,cb>>LTO_GP);
+                cr=wadd(cr,ir); cg=wadd(cg,ig); cb=wadd(cb,ib);
+                c->passes++;
+            }
+            tx=wadd(tx,itx); ty=wadd(ty,ity); cz=wadd(cz,iz);
+        }
+    }
+}
+
+/* texture coordinate at perspective-space column x of one row,
+ * GraphicsPoly.cpp:618-622 / 630-634 */
+static void prp_point(i32 x,i32 xx,i32 yy,i32 zz,i32 ui,i32 vi,i32 zi,int lf,int log_scale,
+                      i32 u0,i32 v0,i32 *tx,i32 *ty)
+{
+    i32 zzz=wadd(zz,wmul(x,zi)>>lf);
+    if(zzz!=0)
+    {
+        *tx=wadd(wshl(tdiv(wshl(wadd(xx,wmul(x,ui)>>lf),log_scale),zzz),LTO_GP),u0);
+        *ty=wadd(wshl(tdiv(wshl(wadd(yy,wmul(x,vi)>>lf),log_scale),zzz),LTO_GP),v0);
+    }
+    else { *tx=0; *ty=0; }
+}
+
+/* G_prp_textured_polygon, GraphicsPoly.cpp:520-684 */
+void lto_prp_textured_polygon(lto_ctx *c,const i32 *tuples,int length,const i32 *O,
+                              const i32 *u,const i32 *v,const i32 *texture,
+                              int log_size,int log_scale)
+{
+    i32 mask=wsub(wshl(1,log_size+LTO_GP),1);
+    i32 x0=O[0],y0=O[1],z0=O[2],u0=O[6],v0=O[7];
+    i32 Vx=v[0],Vy=v[1],Vz=v[2],Ux=u[0],Uy=u[1],Uz=u[2];
+    i32 ui,uj,uc,vi,vj,vc,zi,zj,zc;
+    int lf=c->log_focus,row;
+    if(!scan_polygon(c,tuples,length,8,6)) return;
+    if(!(c->miny<c->maxy)) return;
+    ui=wsub(wmul(Vz,y0),wmul(Vy,z0)); uj=wsub(wmul(Vx,z0),wmul(Vz,x0)); uc=wsub(wmul(Vy,x0),wmul(Vx,y0));
+    vi=wsub(wmul(Uy,z0),wmul(Uz,y0)); vj=wsub(wmul(Uz,x0),wmul(Ux,z0)); vc=wsub(wmul(Ux,y0),wmul(Uy,x0));
+    zi=wsub(wmul(Vy,Uz),wmul(Vz,Uy)); zj=wsub(wmul(Vz,Ux),wmul(Vx,Uz)); zc=wsub(wmul(Vx,Uy),wmul(Vy,Ux));
+    for(row=c->miny;row<c->maxy;row++)
+    {
+        i32 beg=c->xs[row],end=c->xe[row],span=wsub(end,beg),x,y,px;
+        i32 cz,cr,cg,cb,iz,ir,ig,ib,tx,ty,itx,ity,etx,ety,xx,yy,zz;
+        size_t pos=(size_t)row*c->w;
+        if(beg==INT_MAX) continue;
+        if(span==0) span=1;
+        px=beg;                                  /* screen column of the next pixel */
+        beg=wsub(beg,c->w/2); x=beg; end=wsub(end,c->w/2); y=row-c->h/2;
+        cr=c->vs[1][row]; ir=tdiv(wsub(c->ve[1][row],cr),span);
+        cg=c->vs[2][row]; ig=tdiv(wsub(c->ve[2][row],cg),span);
+        cb=c->vs[3][row]; ib=tdiv(wsub(c->ve[3][row],cb),span);
+        cz=c->vs[0][row]; iz=tdiv(wsub(c->ve[0][row],cz),span);
+        xx=wadd(wmul(y,uj)>>lf,uc); yy=wadd(wmul(y,vj)>>lf,vc); zz=wadd(wmul(y,zj)>>lf,zc);
+        prp_point(x,xx,yy,zz,ui,vi,zi,lf,log_scale,u0,v0,&etx,&ety);
+        for(;beg<=end;)
+        {
+            x+=LTO_LINEAR; if(x>end) x=end;
+            tx=etx; ty=ety;
+            prp_point(x,xx,yy,zz,ui,vi,zi,lf,log_scale,u0,v0,&etx,&ety);
+            if((span=x-beg)!=0){ itx=tdiv(wsub(etx,tx),span); ity=tdiv(wsub(ety,ty),span); }
+            else { itx=ity=0; }
+            for(;beg<=x;beg++,px++)
+            {
+                tx&=mask; ty&=mask;
+                c->fragments++;
+                if(c->zbuf[pos+px]>(cz>>LTO_GP))
+                {
+                    c->zbuf[pos+px]=cz>>LTO_GP;
+                    c->cbuf[pos+px]=lto_cl_light(texture[((ty>>LTO_GP)<<log_size)+(tx>>LTO_GP)],
+                                                 cr>>LTO_GP,cg>>LTO_GP,cb>>LTO_GP);
+                    cr=wadd(cr,ir); cg=wadd(cg,ig); cb=wadd(cb,ib);
+                    c->passes++;
+                }
+                tx=wadd(tx,itx); ty=wadd(ty,ity); cz=wadd(cz,iz);
+            }
+        }
+    }
+}
+
+/* kind: 2 flat, 4 shaded, 8 linear textured */
+void lto_g_polygon(lto_ctx *c,int kind,const i32 *tuples,int length,i32 colour,
+                   i32 r,i32 g,i32 b,int tex)
+{
+    if(kind==LTO_M_FLAT) lto_flat_polygon(c,tuples,length,colour,r,g,b);
+    else if(kind==LTO_M_SHADED) lto_shaded_polygon(c,tuples,length,colour);
+    else lto_lin_textured_polygon(c,tuples,length,c->tex[tex],c->tex_log[tex]);
+}
+
+void lto_g_prp_polygon(lto_ctx *c,const i32 *tuples,int length,const i32 *O,const i32 *u,
+                       const i32 *v,int tex,int log_scale,int log_focus)
+{
+    c->log_focus=log_focus;
+    lto_prp_textured_polygon(c,tuples,length,O,u,v,c->tex[tex],c->tex_log[tex],log_scale);
+}
+
+/* ------------------------------------------------------------------ engine */
+
+/* T_linear_solve, TransBs.cpp:440-515 (fixed-point branch), n x n system, m right
+ * hand sides.  Returns 0 where the reference would divide by zero. */
+static int linear_solve(i32 ia[8][8],i32 ib[8][8],i32 ix[8][8],int n,int m,int log_src,int log_res)
+{
+    i32 a[8][8],b[8][8],x[8][8],max,tmp,pivot,sum;
+    int i,j,k,num;
+    for(i=0;i<n;i++)
+    {
+        for(j=0;j<n;j++) a[i][j]=ia[i][j]>>log_src;
+        for(j=0;j<m;j++) b[i][j]=ib[i][j];
+    }
+    for(max=0,num=0,i=0;i<n-1;i++)
+    {
+        for(j=i;j<n;j++)
+        {
+            if(a[j][i]>=0) pivot=a[j][i]; else pivot=-a[j][i];
+            if(pivot>max){ max=pivot; num=j; }
+        }
+        if(max!=0)
+        {
+            if(num!=i)
+            {
+                for(j=0;j<n;j++){ tmp=a[i][j]; a[i][j]=a[num][j]; a[num][j]=tmp; }
+                for(j=0;j<m;j++){ tmp=b[i][j]; b[i][j]=b[num][j]; b[num][j]=tmp; }
+            }
+            for(j=i+1;j<n;j++)
+            {
+                if(a[i][i]==0) return 0;
+                for(k=i+1;k<n;k++) a[j][k]=wsub(a[j][k],tdiv(wmul(a[i][k],a[j][i]),a[i][i]));
+                for(k=0;k<m;k++)   b[j][k]=wsub(b[j][k],tdiv(wmul(b[i][k],a[j][i]),a[i][i]));
+            }
+        }
+    }
+    for(i=n-1;i>=0;i--)
+    {
+        for(k=0;k<m;k++)
+        {
+            for(sum=0,j=i+1;j<n;j++) sum=wadd(sum,wmul(a[i][j],x[j][k])>>log_res);
+            if(a[i][i]==0) return 0;
+            x[i][k]=tdiv(wshl(wsub(b[i][k],sum),log_res),a[i][i]);
+            ix[i][k]=x[i][k];
+        }
+    }
+    return 1;
+}
+
+/* MI_tmapping_vectors, EngBase.cpp:145-179; p1..p3 are M_LNG_TEXTURED tuples */
+static int tmapping_vectors(int type,const i32 *p1,const i32 *p2,const i32 *p3,
+                            int log_space,i32 *u,i32 *v)
+{
+    int j;
+    if(type)
+    {
+        if(type&LTO_M_QUAD_XY){ for(j=0;j<3;j++){ u[j]=wsub(p2[j],p1[j]); v[j]=wsub(p3[j],p2[j]); } }
+        else                  { for(j=0;j<3;j++){ u[j]=wsub(p1[j],p2[j]); v[j]=wsub(p2[j],p3[j]); } }
+        return 1;
+    }
+    else
+    {
+        i32 a[8][8],b[8][8],x[8][8];
+        memset(a,0,sizeof(a)); memset(b,0,sizeof(b)); memset(x,0,sizeof(x));
+        for(j=0;j<2;j++){ a[0][j]=wsub(p2[6+j],p1[6+j]); a[1][j]=wsub(p3[6+j],p2[6+j]); }
+        for(j=0;j<3;j++){ b[0][j]=wsub(p2[j],p1[j]); b[1][j]=wsub(p3[j],p2[j]); }
+        if(!linear_solve(a,b,x,2,3,LTO_GP,log_space)) return 0;
+        for(j=0;j<3;j++){ u[j]=x[0][j]; v[j]=x[1][j]; }
+        return 1;
+    }
+}
+
+/* CI_construct_tuples (EngBase.cpp:47-138, colours==NULL, textures==NULL) for one
+ * polygon: rec = M_polygon.m_vertices records [Idx R G B Tx Ty]. */
+static void construct_tuples(const i32 *rec,i32 *to,const i32 *verts,int dim,int len,i32 *mn,i32 *mx)
+{
+    int i,j;
+    for(j=0;j<3;j++){ mn[j]=INT_MAX; mx[j]=INT_MIN; }
+    for(i=0;i<len;i++,rec+=6,to+=dim)
+    {
+        const i32 *p=verts+(size_t)rec[0]*4;
+        for(j=0;j<3;j++)
+        {
+            to[j]=p[j];
+            if(to[j]>mx[j]) mx[j]=to[j];
+            if(to[j]<mn[j]) mn[j]=to[j];
+        }
+        if(dim>=6){ to[3]=wshl(rec[1],LTO_GP); to[4]=wshl(rec[2],LTO_GP); to[5]=wshl(rec[3],LTO_GP); }
+        if(dim==8){ to[6]=wshl(rec[4],LTO_GP); to[7]=wshl(rec[5],LTO_GP); }
+    }
+}
+
+/* M_render_polygon, EngBase.cpp:379-552, for one polygon of the flat scene layout.
+ * polys[i] = {colour, texture handle or -1, no_edges, first};
+ * polyaux[i] = {m_red, m_green, m_blue, m_type | log_texture_space_size<<8}. */
+static void render_polygon(lto_ctx *c,const i32 *viewverts,const i32 *poly,const i32 *aux,
+                           const i32 *polyverts,int render_type,int force_linear)
+{
+    i32 original1[LTO_WORK_TUPLES*LTO_MAX_DIM+LTO_MAX_DIM];
+    i32 original2[LTO_WORK_TUPLES*LTO_MAX_DIM+LTO_MAX_DIM];
+    i32 persp[LTO_WORK_TUPLES*LTO_MAX_DIM+LTO_MAX_DIM];
+    i32 mn[3],mx[3],u[4],v[4],*clipped;
+    const i32 *rec=polyverts+(size_t)poly[3]*6;
+    int number=poly[2],cnd,dim,kind=render_type;
+
+    c->polys_in++;
+    if(number+1>LTO_MAX_TUPLES){ c->overflow++; return; }
+    if(kind==LTO_M_TEXTURED&&poly[1]<0) kind=LTO_M_SHADED;      /* EngBase.cpp:470,518-522 */
+    if(kind==LTO_M_FLAT) dim=3; else if(kind==LTO_M_SHADED) dim=6; else if(kind==LTO_M_TEXTURED) dim=8;
+    else { c->unsupported++; return; }                          /* M_WIRE: G_line is outside this path */
+
+    construct_tuples(rec,original1,viewverts,dim,number+1,mn,mx);
+    if((cnd=lto_volume_clipping(mn,mx))==0) return;
+    if(cnd==-1)
+    {
+        number=clip_polygon(c,2,original1,original2,dim,number);
+        if(number+1>LTO_MAX_TUPLES){ c->overflow++; return; }
+        clipped=original2;
+    }
+    else clipped=original1;
+    /* With fewer than two edges left the reference's back-face test reads tuples it
+     * never wrote (EngBase.cpp:541-543); that cannot happen for a closed polygon that
+     * passed the volume test, and is dropped here and in the HIP path. */
+    if(number<2) return;
+    lto_perspective(c,clipped,persp,dim,number+1,c->log_focus);
+    if(!lto_normal_z_negative(persp,persp+dim,persp+2*dim)) return;
+    c->polys_drawn++;
+    if(kind==LTO_M_FLAT)
+        lto_flat_polygon(c,persp,number,poly[0],aux?aux[0]:0,aux?aux[1]:0,aux?aux[2]:0);
+    else if(kind==LTO_M_SHADED)
+        lto_shaded_polygon(c,persp,number,poly[0]);
+    else
+    {
+        if(force_linear||(clipped[2]<LTO_Z_SWITCH))              /* EngBase.cpp:491-493 */
+        {
+            int type=aux?(aux[3]&0xff):0,log_space=aux?(aux[3]>>8):0;
+            if(!tmapping_vectors(type&LTO_M_QUAD,original1,original1+8,original1+16,log_space,u,v))
+            { c->unsupported++; return; }
+            lto_prp_textured_polygon(c,persp,number,clipped,u,v,c->tex[poly[1]],c->tex_log[poly[1]],log_space);
+        }
+        else lto_lin_textured_polygon(c,persp,number,c->tex[poly[1]],c->tex_log[poly[1]]);
+    }
+}
+
+/* The polygon loop of M_render_polygon_object (EngPoly.cpp:518-523) over vertices
+ * that lto_transform has already moved into view space. */
+void lto_render_polys(lto_ctx *c,const i32 *viewverts,const i32 *polys,const i32 *polyaux,
+                      const i32 *polyverts,int np,int render_type,int log_focus,int force_linear)
+{
+    int i;
+    c->log_focus=log_focus;
+    for(i=0;i<np;i++)
+        render_polygon(c,viewverts,polys+(size_t)i*4,polyaux?polyaux+(size_t)i*4:NULL,
+                       polyverts,render_type,force_linear);
+}

@@ -1,0 +1,164 @@
+"""ctypes wrapper around the checker libraries built from the reference's own sources.
+
+oracle/build_ref.sh compiles the reference where it lies under /root/reference into
+oracle/_ref/libltref_<W>x<H>_<tables>.so (one per screen size: the reference fixes it
+at compile time).  The libraries travel with the tree; the sources never do.  Where
+neither a prebuilt library nor the reference tree is present, `available()` is False
+and callers skip.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_REFDIR = os.environ.get("LT_REFERENCE_DIR", "/root/reference")
+
+I32P = C.POINTER(C.c_int32)
+
+
+def so_path(w, h, tables="trans"):
+    return os.path.join(_HERE, "_ref", f"libltref_{w}x{h}_{tables}.so")
+
+
+def available(w, h, tables="trans"):
+    return os.path.exists(so_path(w, h, tables)) or os.path.isdir(_REFDIR)
+
+
+def build(w, h, tables="trans"):
+    p = so_path(w, h, tables)
+    if not os.path.exists(p):
+        subprocess.check_call([os.path.join(_HERE, "build_ref.sh"), str(w), str(h), tables])
+    return p
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+_libs = {}
+
+
+class Ref:
+    """The reference's own code at one compile-time screen size.  Its state is global
+    to the loaded library (as in the reference), so there is one instance per size."""
+
+    def __new__(cls, w, h, tables="trans"):
+        key = (w, h, tables)
+        if key in _libs:
+            return _libs[key]
+        self = super().__new__(cls)
+        L = C.CDLL(build(w, h, tables))
+        L.ltref_cbuf.restype = I32P
+        L.ltref_zbuf.restype = I32P
+        for f in ("ltref_cl_light", "ltref_cl_colour", "ltref_volume_clipping", "ltref_polygon_z_clipping",
+                  "ltref_polygon_x_clipping", "ltref_normal_z_negative", "ltref_line_clipping"):
+            getattr(L, f).restype = C.c_int
+        L.ltref_init()
+        assert L.ltref_width() == w and L.ltref_height() == h
+        self.L, self.w, self.h = L, w, h
+        _libs[key] = self
+        return self
+
+    def clear(self, colour, r, g, b):
+        self.L.ltref_clear(C.c_int(colour), r, g, b)
+
+    def cbuf(self):
+        return np.ctypeslib.as_array(self.L.ltref_cbuf(), shape=(self.h, self.w))
+
+    def zbuf(self):
+        return np.ctypeslib.as_array(self.L.ltref_zbuf(), shape=(self.h, self.w))
+
+    def cl_light(self, colour, r, g, b):
+        return self.L.ltref_cl_light(C.c_int(colour), r, g, b)
+
+    def cl_colour(self, r, g, b):
+        return self.L.ltref_cl_colour(r, g, b)
+
+    def trig_tables(self):
+        s, c = np.zeros(256, np.int32), np.zeros(256, np.int32)
+        self.L.ltref_trig_tables(_p(s), _p(c))
+        return s, c
+
+    def set_texture(self, handle, texels, log_size):
+        t = _i32(texels).reshape(-1)
+        self.L.ltref_set_texture(handle, _p(t), log_size)
+
+    def make_matrix(self, cam=(0, 0, 0, 0, 0, 0), obj=(0, 0, 0, 0, 0, 0), log_focus=8):
+        m = np.zeros(12, np.int32)
+        self.L.ltref_make_matrix(cam[0], cam[1], cam[2], cam[3], cam[4], cam[5], log_focus,
+                                 obj[0], obj[1], obj[2], obj[3], obj[4], obj[5], _p(m))
+        return m
+
+    def transform(self, m12, verts):
+        v = _i32(verts).reshape(-1, 4).copy()
+        out = v.copy()
+        m = _i32(m12)
+        self.L.ltref_set_matrix(_p(m))
+        self.L.ltref_transform(_p(v), _p(out), v.shape[0])
+        return out
+
+    def perspective(self, tuples, dim, log_focus):
+        t = _i32(tuples).reshape(-1, dim).copy()
+        out = np.zeros_like(t)
+        self.L.ltref_perspective(_p(t), _p(out), dim, t.shape[0], log_focus)
+        return out
+
+    def normal_z_negative(self, a, b, c):
+        a, b, c = _i32(a).copy(), _i32(b).copy(), _i32(c).copy()
+        return self.L.ltref_normal_z_negative(_p(a), _p(b), _p(c))
+
+    def volume_clipping(self, mn, mx):
+        mn, mx = _i32(mn).copy(), _i32(mx).copy()
+        return self.L.ltref_volume_clipping(_p(mn), _p(mx))
+
+    def line_clipping(self, axis, v1, v2):
+        v1, v2 = _i32(v1).copy(), _i32(v2).copy()
+        dim = v1.size
+        o1, o2 = np.zeros(dim, np.int32), np.zeros(dim, np.int32)
+        moved = C.c_int(0)
+        r = self.L.ltref_line_clipping(axis, _p(v1), _p(v2), dim, _p(o1), _p(o2), C.byref(moved))
+        return r, o1, o2, moved.value
+
+    def polygon_clipping(self, axis, tuples, dim):
+        t = _i32(tuples).reshape(-1, dim).copy()
+        out = np.zeros((65, dim), np.int32)     # the reference's own arrays hold 16
+        f = self.L.ltref_polygon_z_clipping if axis == 2 else self.L.ltref_polygon_x_clipping
+        n = f(_p(t), _p(out), dim, t.shape[0] - 1)
+        return n, out[: n + 1].copy()
+
+    def scan_polygon(self, tuples, dim):
+        t = _i32(tuples).reshape(-1, dim).copy()
+        xs = np.zeros(self.h, np.int32)
+        xe = np.zeros(self.h, np.int32)
+        vs = np.zeros((self.h, 6), np.int32)
+        ve = np.zeros((self.h, 6), np.int32)
+        mn, mx = C.c_int(0), C.c_int(0)
+        self.L.ltref_scan_polygon(_p(t), t.shape[0] - 1, dim, C.byref(mn), C.byref(mx), _p(xs), _p(xe), _p(vs), _p(ve))
+        return mn.value, mx.value, xs, xe, vs, ve
+
+    def g_polygon(self, kind, tuples, colour=0, r=0, g=0, b=0, tex=0):
+        dim = {2: 3, 4: 6, 8: 8}[kind]
+        t = _i32(tuples).reshape(-1, dim).copy()
+        self.L.ltref_g_polygon(kind, _p(t), t.shape[0] - 1, C.c_int(colour), r, g, b, tex)
+
+    def g_prp_polygon(self, tuples, O, u, v, tex, log_scale, log_focus):
+        t = _i32(tuples).reshape(-1, 8).copy()
+        O, u, v = _i32(O).copy(), _i32(u).copy(), _i32(v).copy()
+        self.L.ltref_g_prp_polygon(_p(t), t.shape[0] - 1, _p(O), _p(u), _p(v), tex, log_scale, log_focus)
+
+    def render_polys(self, viewverts, polys, polyaux, polyverts, render_type, log_focus, force_linear=0):
+        vv, po, pv = _i32(viewverts).copy(), _i32(polys), _i32(polyverts).copy()
+        pa = None if polyaux is None else _i32(polyaux)
+        self.L.ltref_render_polys(_p(vv), _p(po), _p(pa), _p(pv), po.shape[0], render_type, log_focus, force_linear)
+
+    def render_object(self, verts, polys, polyaux, polyverts, render_type, pos, ang):
+        v, po, pv = _i32(verts).copy(), _i32(polys), _i32(polyverts).copy()
+        pa = None if polyaux is None else _i32(polyaux)
+        self.L.ltref_render_object(_p(v), v.shape[0], _p(po), _p(pa), _p(pv), po.shape[0], render_type,
+                                   pos[0], pos[1], pos[2], ang[0], ang[1], ang[2])

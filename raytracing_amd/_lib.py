@@ -1,0 +1,60 @@
+"""Loader of libltgpu.so, the HIP library behind include/lt_gpu.h.
+
+There is no CPU fallback: if the library has not been built (see
+__graft_entry__.build) importing anything that draws raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libltgpu.so")
+
+EXPORTS = [
+    "lt_ctx_create", "lt_ctx_destroy", "lt_last_error", "lt_set_stream", "lt_set_list_capacity",
+    "lt_clear", "lt_flush", "lt_readback", "lt_framebuffer", "lt_get_counters", "lt_reset_counters",
+    "lt_texture_upload", "lt_transform", "lt_submit_object", "lt_submit_object_dev",
+    "lt_submit_screen_polys",
+]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "fragments", "polys_in", "polys_drawn", "tile_refs", "overflow_polys",
+        "order_dependent_rows", "unsupported_polys", "list_overflow")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    L = C.CDLL(SO_PATH)
+    vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+    L.lt_ctx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.lt_ctx_destroy.argtypes = [vp]
+    L.lt_last_error.argtypes = [vp]
+    L.lt_last_error.restype = C.c_char_p
+    L.lt_set_stream.argtypes = [vp, vp]
+    L.lt_set_list_capacity.argtypes = [vp, u64]
+    L.lt_clear.argtypes = [vp, C.c_int32]
+    L.lt_flush.argtypes = [vp]
+    L.lt_readback.argtypes = [vp, vp, vp]
+    L.lt_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.lt_get_counters.argtypes = [vp, C.POINTER(Counters)]
+    L.lt_reset_counters.argtypes = [vp]
+    L.lt_texture_upload.argtypes = [vp, i32, vp, i32]
+    L.lt_transform.argtypes = [vp, vp, vp, vp, i32]
+    L.lt_submit_object.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
+    L.lt_submit_object_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
+    L.lt_submit_screen_polys.argtypes = [vp, i32, vp, i32, vp, i32, i32]
+    for name in EXPORTS:
+        if name != "lt_last_error":
+            getattr(L, name).restype = i32
+    _lib = L
+    return L

@@ -1,0 +1,436 @@
+// C-ABI of libltgpu.so (include/lt_gpu.h): context, framebuffer and the entry points of
+// the polygon path.  Host code only; the kernels are in lt_kernels.hip.
+#include "../../include/lt_gpu.h"
+#include "lt_kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace lt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct lt_ctx {
+    int device = 0;
+    int W = 0, H = 0, tiles_x = 0, tiles_y = 0, ntiles = 0;
+    hipStream_t stream = nullptr;
+    int *cbuf = nullptr, *zbuf = nullptr;
+    bool clear_pending = false;
+    int clear_colour = 0;
+    bool frame_defined = false;
+    Status *status = nullptr;          // device
+    Status base{};                     // host copy at the last reset
+    uint64_t polys_in = 0;
+    uint64_t list_capacity_user = 0;
+    // per-submit workspace (grown on demand, reused)
+    DevBuf view, hdr, edges, list, tcount, toffset, tcursor;
+    DevBuf s_verts, s_polys, s_aux, s_pv;      // staging for host-pointer submits
+    // textures
+    int *tex_data[LT_MAX_TEXTURES] = {};
+    int tex_log_h[LT_MAX_TEXTURES] = {};
+    const int **tex_ptr_d = nullptr;
+    int *tex_log_d = nullptr;
+    bool order_warned = false;
+    std::string err;
+};
+
+namespace {
+
+int fail(lt_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                        \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) return fail(c, LT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int ensure(lt_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return LT_OK;
+    if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return LT_OK;
+}
+
+int use_device(lt_ctx *c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    return LT_OK;
+}
+
+// set-up -> scan -> bin -> fill for one batch whose polygon data is on the device
+int run_batch(lt_ctx *c, bool screen, int dim, const int *d_verts, int nv, const int *d_polys, const int *d_aux,
+              int np, const int *d_pv, int npv, int render_type, int log_focus, int force_linear, int max_edges)
+{
+    const int na = dim - 2;
+    if (max_edges <= 0 || max_edges > 15) max_edges = 15;
+    int emax = (screen ? 2 : 4) * max_edges;
+    if (emax > 15) emax = 15;
+    uint64_t capacity = c->list_capacity_user ? c->list_capacity_user : (uint64_t)np * 64u;
+    if (capacity < (1u << 20)) capacity = 1u << 20;
+
+    int rc;
+    if ((rc = ensure(c, c->hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
+    if ((rc = ensure(c, c->edges, (size_t)np * emax * edge_ints(na) * sizeof(int)))) return rc;
+    if ((rc = ensure(c, c->list, (size_t)capacity * sizeof(unsigned)))) return rc;
+    if ((rc = ensure(c, c->tcount, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
+    if ((rc = ensure(c, c->toffset, (size_t)(c->ntiles + 1) * sizeof(unsigned)))) return rc;
+    if ((rc = ensure(c, c->tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
+
+    HIPCHK(c, hipMemsetAsync(c->tcount.p, 0, (size_t)c->ntiles * sizeof(unsigned), c->stream));
+
+    SetupArgs sa{};
+    sa.verts = d_verts; sa.polys = d_polys; sa.polyaux = d_aux; sa.polyverts = d_pv;
+    sa.np = np; sa.nv = nv; sa.npv = npv;
+    sa.render_type = render_type; sa.log_focus = log_focus; sa.force_linear = force_linear;
+    sa.max_edges = max_edges;
+    sa.W = c->W; sa.H = c->H; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+    sa.emax = emax;
+    sa.hdr = (PrimHdr *)c->hdr.p; sa.edges = (int *)c->edges.p;
+    sa.tile_count = (unsigned *)c->tcount.p; sa.status = c->status;
+    launch_setup(c->stream, dim, screen, sa);
+
+    launch_scan(c->stream, (const unsigned *)c->tcount.p, (unsigned *)c->toffset.p, (unsigned *)c->tcursor.p,
+                c->ntiles, capacity, c->status);
+    launch_bin(c->stream, (const PrimHdr *)c->hdr.p, np, c->tiles_x, (const unsigned *)c->toffset.p,
+               (unsigned *)c->tcursor.p, (unsigned *)c->list.p, capacity, c->status);
+
+    RasterArgs ra{};
+    ra.hdr = (const PrimHdr *)c->hdr.p; ra.edges = (const int *)c->edges.p;
+    ra.tile_offset = (const unsigned *)c->toffset.p; ra.tile_fill = (const unsigned *)c->tcursor.p;
+    ra.tile_list = (const unsigned *)c->list.p; ra.list_capacity = capacity;
+    ra.emax = emax;
+    ra.W = c->W; ra.H = c->H; ra.tiles_x = c->tiles_x; ra.tiles_y = c->tiles_y;
+    ra.cbuf = c->cbuf; ra.zbuf = c->zbuf;
+    ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
+    ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
+    ra.status = c->status;
+    launch_raster(c->stream, na, ra);
+    HIPCHK(c, hipGetLastError());
+
+    c->clear_pending = false;
+    c->frame_defined = true;
+    c->polys_in += (uint64_t)np;
+    return LT_OK;
+}
+
+int check_type(lt_ctx *c, int render_type, int *dim)
+{
+    if (render_type == LT_FLAT) *dim = 3;
+    else if (render_type == LT_SHADED) *dim = 6;
+    else if (render_type == LT_TEXTURED) *dim = 8;
+    else return fail(c, LT_ERR_ARG, "render type %d: only LT_FLAT, LT_SHADED and LT_TEXTURED are drawn by this path", render_type);
+    return LT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lt_ctx_create(int device, int width, int height, lt_ctx **out)
+{
+    if (!out) return fail(nullptr, LT_ERR_ARG, "lt_ctx_create: out is NULL");
+    *out = nullptr;
+    if (width < 2 || height < 2 || width > LT_MAX_SCREEN || height > LT_MAX_SCREEN)
+        return fail(nullptr, LT_ERR_ARG, "lt_ctx_create: screen %dx%d outside 2..%d", width, height, LT_MAX_SCREEN);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, LT_ERR_HIP, "lt_ctx_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, LT_ERR_ARG, "lt_ctx_create: device %d of %d", device, ndev);
+    lt_ctx *c = new lt_ctx();
+    c->device = device;
+    c->W = width; c->H = height;
+    c->tiles_x = (width + TW - 1) / TW; c->tiles_y = (height + TH - 1) / TH;
+    c->ntiles = c->tiles_x * c->tiles_y;
+    size_t n = (size_t)width * height;
+#define CREATECHK(call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            int rc_ = fail(nullptr, LT_ERR_HIP, "lt_ctx_create: %s: %s", #call, hipGetErrorString(e_));   \
+            lt_ctx_destroy(c);                                                                            \
+            return rc_;                                                                                   \
+        }                                                                                                 \
+    } while (0)
+    CREATECHK(hipSetDevice(device));
+    CREATECHK(hipMalloc((void **)&c->cbuf, n * sizeof(int)));
+    CREATECHK(hipMalloc((void **)&c->zbuf, n * sizeof(int)));
+    CREATECHK(hipMalloc((void **)&c->status, sizeof(Status)));
+    CREATECHK(hipMemset(c->status, 0, sizeof(Status)));
+    CREATECHK(hipMalloc((void **)&c->tex_ptr_d, sizeof(int *) * LT_MAX_TEXTURES));
+    CREATECHK(hipMalloc((void **)&c->tex_log_d, sizeof(int) * LT_MAX_TEXTURES));
+    CREATECHK(hipMemset((void *)c->tex_ptr_d, 0, sizeof(int *) * LT_MAX_TEXTURES));
+    CREATECHK(hipMemset(c->tex_log_d, 0, sizeof(int) * LT_MAX_TEXTURES));
+#undef CREATECHK
+    // the frame's contents are undefined until lt_clear, as after G_init_graphics
+    *out = c;
+    return LT_OK;
+}
+
+int lt_ctx_destroy(lt_ctx *c)
+{
+    if (!c) return LT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *bufs[] = {&c->view, &c->hdr, &c->edges, &c->list, &c->tcount, &c->toffset, &c->tcursor,
+                      &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < LT_MAX_TEXTURES; i++)
+        if (c->tex_data[i]) (void)hipFree(c->tex_data[i]);
+    if (c->cbuf) (void)hipFree(c->cbuf);
+    if (c->zbuf) (void)hipFree(c->zbuf);
+    if (c->status) (void)hipFree(c->status);
+    if (c->tex_ptr_d) (void)hipFree((void *)c->tex_ptr_d);
+    if (c->tex_log_d) (void)hipFree(c->tex_log_d);
+    delete c;
+    return LT_OK;
+}
+
+const char *lt_last_error(lt_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int lt_set_stream(lt_ctx *c, void *hip_stream)
+{
+    if (!c) return LT_ERR_ARG;
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stream = (hipStream_t)hip_stream;
+    return LT_OK;
+}
+
+int lt_set_list_capacity(lt_ctx *c, uint64_t refs)
+{
+    if (!c) return LT_ERR_ARG;
+    c->list_capacity_user = refs;
+    return LT_OK;
+}
+
+int lt_clear(lt_ctx *c, int32_t lit_colour)
+{
+    if (!c) return LT_ERR_ARG;
+    c->clear_pending = true;
+    c->clear_colour = lit_colour;
+    c->frame_defined = true;
+    return LT_OK;
+}
+
+static int materialize_clear(lt_ctx *c)
+{
+    if (c->clear_pending) {
+        launch_fill(c->stream, c->cbuf, c->zbuf, (size_t)c->W * c->H, c->clear_colour);
+        HIPCHK(c, hipGetLastError());
+        c->clear_pending = false;
+    }
+    return LT_OK;
+}
+
+int lt_flush(lt_ctx *c)
+{
+    if (!c) return LT_ERR_ARG;
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = materialize_clear(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Status s;
+    HIPCHK(c, hipMemcpy(&s, c->status, sizeof s, hipMemcpyDeviceToHost));
+    if (s.list_overflow > c->base.list_overflow) {
+        c->base.list_overflow = s.list_overflow;
+        return fail(c, LT_ERR_CAPACITY,
+                    "tile lists overflowed by %llu references: the frame is incomplete; raise lt_set_list_capacity",
+                    (unsigned long long)s.list_overflow);
+    }
+    if (s.overflow_polys > c->base.overflow_polys) {
+        unsigned long long d = s.overflow_polys - c->base.overflow_polys;
+        c->base.overflow_polys = s.overflow_polys;
+        return fail(c, LT_ERR_OVERFLOW,
+                    "%llu polygon(s) outside the limits (fewer than 2 or more than max_edges edges, a vertex index "
+                    "out of range, or more than 16 tuples after clipping) were not drawn", d);
+    }
+    if (s.unsupported_polys > c->base.unsupported_polys) {
+        unsigned long long d = s.unsupported_polys - c->base.unsupported_polys;
+        c->base.unsupported_polys = s.unsupported_polys;
+        return fail(c, LT_ERR_UNSUPPORTED,
+                    "%llu textured polygon(s) take the reference's perspective mapper (first vertex z < 1024 or "
+                    "M_force_linear_tmapping set) or name a bad texture: not drawn", d);
+    }
+    if (s.order_dependent_rows > c->base.order_dependent_rows) {
+        unsigned long long d = s.order_dependent_rows - c->base.order_dependent_rows;
+        c->base.order_dependent_rows = s.order_dependent_rows;
+        return fail(c, LT_ERR_UNSUPPORTED,
+                    "%llu textured row(s) have a light gradient: the reference advances light only on depth-test "
+                    "passes there, which depends on draw history; drawn as if every earlier pixel had passed", d);
+    }
+    return LT_OK;
+}
+
+int lt_readback(lt_ctx *c, int32_t *colour, int32_t *depth)
+{
+    if (!c) return LT_ERR_ARG;
+    if (!c->frame_defined) return fail(c, LT_ERR_ARG, "lt_readback before the first lt_clear: the frame is undefined");
+    int rc = lt_flush(c);
+    size_t bytes = (size_t)c->W * c->H * sizeof(int);
+    if (colour) HIPCHK(c, hipMemcpy(colour, c->cbuf, bytes, hipMemcpyDeviceToHost));
+    if (depth) HIPCHK(c, hipMemcpy(depth, c->zbuf, bytes, hipMemcpyDeviceToHost));
+    return rc;
+}
+
+int lt_framebuffer(lt_ctx *c, int32_t **d_colour, int32_t **d_depth)
+{
+    if (!c) return LT_ERR_ARG;
+    if (d_colour) *d_colour = c->cbuf;
+    if (d_depth) *d_depth = c->zbuf;
+    return LT_OK;
+}
+
+int lt_get_counters(lt_ctx *c, lt_counters *out)
+{
+    if (!c || !out) return LT_ERR_ARG;
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Status s;
+    HIPCHK(c, hipMemcpy(&s, c->status, sizeof s, hipMemcpyDeviceToHost));
+    out->fragments = s.fragments;
+    out->polys_in = c->polys_in;
+    out->polys_drawn = s.polys_drawn;
+    out->tile_refs = s.tile_refs;
+    out->overflow_polys = s.overflow_polys;
+    out->order_dependent_rows = s.order_dependent_rows;
+    out->unsupported_polys = s.unsupported_polys;
+    out->list_overflow = s.list_overflow;
+    return LT_OK;
+}
+
+int lt_reset_counters(lt_ctx *c)
+{
+    if (!c) return LT_ERR_ARG;
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(Status), c->stream));
+    c->base = Status{};
+    c->polys_in = 0;
+    return LT_OK;
+}
+
+int lt_texture_upload(lt_ctx *c, int handle, const int32_t *texels, int log_size)
+{
+    if (!c || !texels) return LT_ERR_ARG;
+    if (handle < 0 || handle >= LT_MAX_TEXTURES) return fail(c, LT_ERR_ARG, "texture handle %d outside 0..%d", handle, LT_MAX_TEXTURES - 1);
+    if (log_size < 0 || log_size > 12) return fail(c, LT_ERR_ARG, "texture log size %d outside 0..12", log_size);
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->tex_data[handle]) { HIPCHK(c, hipFree(c->tex_data[handle])); c->tex_data[handle] = nullptr; }
+    size_t bytes = sizeof(int) << (2 * log_size);
+    HIPCHK(c, hipMalloc((void **)&c->tex_data[handle], bytes));
+    HIPCHK(c, hipMemcpy(c->tex_data[handle], texels, bytes, hipMemcpyHostToDevice));
+    c->tex_log_h[handle] = log_size;
+    HIPCHK(c, hipMemcpy((void *)(c->tex_ptr_d + handle), &c->tex_data[handle], sizeof(int *), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->tex_log_d + handle, &log_size, sizeof(int), hipMemcpyHostToDevice));
+    return LT_OK;
+}
+
+int lt_transform(lt_ctx *c, const int32_t m[12], const int32_t *d_from, int32_t *d_to, int n)
+{
+    if (!c || !m || n < 0 || (n > 0 && (!d_from || !d_to))) return fail(c, LT_ERR_ARG, "lt_transform: bad argument");
+    int rc = use_device(c);
+    if (rc) return rc;
+    launch_transform(c->stream, m, d_from, d_to, n);
+    HIPCHK(c, hipGetLastError());
+    return LT_OK;
+}
+
+int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts, int nv, const int32_t *d_polys,
+                         const int32_t *d_polyaux, int np, const int32_t *d_polyverts, int npv, int render_type,
+                         int log_focus, int force_linear, int max_edges)
+{
+    if (!c) return LT_ERR_ARG;
+    int dim = 0, rc;
+    if ((rc = check_type(c, render_type, &dim))) return rc;
+    if (np < 0 || nv < 0 || npv < 0 || !m) return fail(c, LT_ERR_ARG, "lt_submit_object: negative count or NULL matrix");
+    if (np == 0) return LT_OK;
+    if (!d_verts || !d_polys || !d_polyverts) return fail(c, LT_ERR_ARG, "lt_submit_object: NULL array");
+    if (render_type == LT_FLAT && !d_polyaux) return fail(c, LT_ERR_ARG, "lt_submit_object: LT_FLAT needs polyaux (m_red, m_green, m_blue)");
+    if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_submit_object: log_focus %d outside 0..30", log_focus);
+    if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
+    if ((rc = use_device(c))) return rc;
+    if ((rc = ensure(c, c->view, (size_t)nv * 4 * sizeof(int)))) return rc;
+    launch_transform(c->stream, m, d_verts, (int *)c->view.p, nv);
+    return run_batch(c, false, dim, (const int *)c->view.p, nv, d_polys, d_polyaux, np, d_polyverts, npv, render_type,
+                     log_focus, force_linear, max_edges);
+}
+
+int lt_submit_object(lt_ctx *c, const int32_t m[12], const int32_t *verts, int nv, const int32_t *polys,
+                     const int32_t *polyaux, int np, const int32_t *polyverts, int npv, int render_type,
+                     int log_focus, int force_linear, int max_edges)
+{
+    if (!c) return LT_ERR_ARG;
+    if (np == 0) return LT_OK;
+    if (np < 0 || nv <= 0 || npv <= 0 || !verts || !polys || !polyverts)
+        return fail(c, LT_ERR_ARG, "lt_submit_object: bad argument");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->s_verts, (size_t)nv * 16))) return rc;
+    if ((rc = ensure(c, c->s_polys, (size_t)np * 16))) return rc;
+    if ((rc = ensure(c, c->s_pv, (size_t)npv * 24))) return rc;
+    if (polyaux && (rc = ensure(c, c->s_aux, (size_t)np * 16))) return rc;
+    // pageable host memory: these copies return once the source has been read
+    HIPCHK(c, hipMemcpyAsync(c->s_verts.p, verts, (size_t)nv * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_polys.p, polys, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_pv.p, polyverts, (size_t)npv * 24, hipMemcpyHostToDevice, c->stream));
+    if (polyaux) HIPCHK(c, hipMemcpyAsync(c->s_aux.p, polyaux, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return lt_submit_object_dev(c, m, (const int *)c->s_verts.p, nv, (const int *)c->s_polys.p,
+                                polyaux ? (const int *)c->s_aux.p : nullptr, np, (const int *)c->s_pv.p, npv,
+                                render_type, log_focus, force_linear, max_edges);
+}
+
+int lt_submit_screen_polys(lt_ctx *c, int kind, const int32_t *tuples, int ntuples, const int32_t *desc, int n,
+                           int max_edges)
+{
+    if (!c) return LT_ERR_ARG;
+    int dim = 0, rc;
+    if ((rc = check_type(c, kind, &dim))) return rc;
+    if (n == 0) return LT_OK;
+    if (n < 0 || ntuples <= 0 || !tuples || !desc) return fail(c, LT_ERR_ARG, "lt_submit_screen_polys: bad argument");
+    if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
+    if ((rc = use_device(c))) return rc;
+    if ((rc = ensure(c, c->s_polys, (size_t)n * 16))) return rc;
+    if ((rc = ensure(c, c->s_pv, (size_t)ntuples * dim * 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_polys.p, desc, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_pv.p, tuples, (size_t)ntuples * dim * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return run_batch(c, true, dim, nullptr, 0, (const int *)c->s_polys.p, nullptr, n, (const int *)c->s_pv.p, ntuples,
+                     kind, 0, 0, max_edges);
+}
+
+}  // extern "C"

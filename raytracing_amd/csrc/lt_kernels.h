@@ -1,0 +1,80 @@
+// Device-side data layout and launch wrappers shared by the kernels (lt_kernels.hip)
+// and the C-ABI (lt_api.cpp side of the same library).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lt {
+
+// Screen tile owned by one workgroup of the fill kernel.  Its depth keys and colours
+// live in LDS for the whole kernel.
+constexpr int TW = 64;            // tile width  (pixels)
+constexpr int TH = 32;            // tile height (rows)
+constexpr int RASTER_THREADS = 256;
+constexpr int SETUP_THREADS = 128;
+
+// Per-polygon header written by the setup kernel (16 bytes).
+//   yy    = miny | maxy<<16   rows [miny, maxy) are filled (GraphicsPoly.cpp:329)
+//   xx    = minx | maxx<<16   column range of the clipped polygon (for binning)
+//   colour: LT_FLAT: lit colour; LT_SHADED: base colour; LT_TEXTURED: base colour
+//   meta  = n_edges | kind<<8 | tex<<16 ; n_edges == 0 marks "nothing to draw"
+struct PrimHdr { int yy, xx, colour, meta; };
+
+// Edge record (ints): {x1|y1<<16, x2|y2<<16, start[NA], inc[NA]} after the y clip of
+// GI_scan (GraphicsPoly.cpp:136).  start[0] = Z1<<16, inc[0] = ((Z2-Z1)<<16)/L; the
+// other values as in GraphicsPoly.cpp:171-176.  NA = 1 (flat), 4 (shaded), 6 (textured).
+__host__ __device__ constexpr int edge_ints(int na) { return 2 + 2 * na; }
+
+// Device status block, read back at lt_flush.
+struct Status {
+    unsigned long long fragments;
+    unsigned long long polys_drawn;
+    unsigned long long tile_refs;
+    unsigned long long overflow_polys;
+    unsigned long long order_dependent_rows;
+    unsigned long long unsupported_polys;
+    unsigned long long list_overflow;
+    unsigned long long pad;
+};
+
+struct SetupArgs {
+    const int *verts;        // view-space int32[nv][4]      (object mode)
+    const int *polys;        // int32[np][4]                  (object mode) / desc (screen mode)
+    const int *polyaux;      // int32[np][4] or null
+    const int *polyverts;    // int32[*][6]                   (object mode) / tuples (screen mode)
+    int np, nv, npv;
+    int render_type, log_focus, force_linear, max_edges;
+    int W, H, tiles_x, tiles_y;
+    int emax;                // edge slots per polygon
+    PrimHdr *hdr;
+    int *edges;
+    unsigned *tile_count;
+    Status *status;
+};
+
+struct RasterArgs {
+    const PrimHdr *hdr;
+    const int *edges;
+    const unsigned *tile_offset;   // exclusive prefix of tile_count, [ntiles+1]
+    const unsigned *tile_fill;     // entries actually written per tile
+    const unsigned *tile_list;
+    unsigned long long list_capacity;
+    int emax;
+    int W, H, tiles_x, tiles_y;
+    int *cbuf, *zbuf;
+    int clear_pending, clear_colour;
+    const int *const *tex_ptr;     // device table of texture base pointers
+    const int *tex_log;            // device table of log sizes
+    Status *status;
+};
+
+void launch_transform(hipStream_t s, const int *m12_dev, const int *from, int *to, int n);
+void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
+void launch_scan(hipStream_t s, const unsigned *count, unsigned *offset, unsigned *cursor, int ntiles,
+                 unsigned long long capacity, Status *status);
+void launch_bin(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, const unsigned *offset,
+                unsigned *cursor, unsigned *list, unsigned long long capacity, Status *status);
+void launch_raster(hipStream_t s, int na, const RasterArgs &a);
+void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
+
+}  // namespace lt

@@ -1,0 +1,138 @@
+"""Thin Python face of the C-ABI (include/lt_gpu.h) for tests, the benchmark and the
+frame-parallel driver.  Host arrays are numpy int32; device arrays are torch int32 CUDA
+tensors (torch is used for device memory and streams only)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .scenes import IDENTITY, Scene
+
+LT_FLAT, LT_SHADED, LT_TEXTURED = 2, 4, 8
+DIM = {LT_FLAT: 3, LT_SHADED: 6, LT_TEXTURED: 8}
+
+
+class LtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lt error {code}: {msg}")
+        self.code = code
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dp(t):
+    """device pointer of a torch tensor (or None)"""
+    if t is None:
+        return None
+    import torch
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """One framebuffer on one GPU."""
+
+    def __init__(self, width, height, device=0):
+        self.L = _lib.lib()
+        self.w, self.h = width, height
+        h = C.c_void_p()
+        rc = self.L.lt_ctx_create(device, width, height, C.byref(h))
+        if rc:
+            raise LtError(rc, self.L.lt_last_error(None).decode())
+        self.h_ctx = h
+
+    def close(self):
+        if getattr(self, "h_ctx", None):
+            self.L.lt_ctx_destroy(self.h_ctx)
+            self.h_ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise LtError(rc, self.L.lt_last_error(self.h_ctx).decode())
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.lt_set_stream(self.h_ctx, C.c_void_p(stream_ptr)))
+
+    def set_list_capacity(self, refs):
+        self._chk(self.L.lt_set_list_capacity(self.h_ctx, refs))
+
+    def clear(self, lit_colour):
+        self._chk(self.L.lt_clear(self.h_ctx, lit_colour))
+
+    def flush(self):
+        self._chk(self.L.lt_flush(self.h_ctx))
+
+    def readback(self, check=True):
+        c = np.empty((self.h, self.w), np.int32)
+        z = np.empty((self.h, self.w), np.int32)
+        rc = self.L.lt_readback(self.h_ctx, _p(c), _p(z))
+        if check:
+            self._chk(rc)
+        return c, z
+
+    def counters(self):
+        cs = _lib.Counters()
+        self._chk(self.L.lt_get_counters(self.h_ctx, C.byref(cs)))
+        return {n: int(getattr(cs, n)) for n, _ in cs._fields_}
+
+    def reset_counters(self):
+        self._chk(self.L.lt_reset_counters(self.h_ctx))
+
+    def texture_upload(self, handle, texels, log_size):
+        t = _i32(texels).reshape(-1)
+        assert t.size == 1 << (2 * log_size)
+        self._chk(self.L.lt_texture_upload(self.h_ctx, handle, _p(t), log_size))
+
+    def transform(self, m12, d_from, d_to):
+        m = _i32(m12)
+        self._chk(self.L.lt_transform(self.h_ctx, _p(m), _dp(d_from), _dp(d_to), d_from.shape[0]))
+
+    def submit_object(self, verts, polys, polyverts, render_type, log_focus, polyaux=None, matrix=None,
+                      force_linear=0, max_edges=0):
+        m = _i32(IDENTITY if matrix is None else matrix)
+        v, po, pv = _i32(verts).reshape(-1, 4), _i32(polys).reshape(-1, 4), _i32(polyverts).reshape(-1, 6)
+        pa = None if polyaux is None else _i32(polyaux).reshape(-1, 4)
+        self._chk(self.L.lt_submit_object(self.h_ctx, _p(m), _p(v), v.shape[0], _p(po), _p(pa), po.shape[0],
+                                          _p(pv), pv.shape[0], render_type, log_focus, force_linear, max_edges))
+
+    def submit_object_dev(self, d_verts, d_polys, d_polyverts, render_type, log_focus, d_polyaux=None,
+                          matrix=None, force_linear=0, max_edges=0):
+        m = _i32(IDENTITY if matrix is None else matrix)
+        self._chk(self.L.lt_submit_object_dev(self.h_ctx, _p(m), _dp(d_verts), d_verts.shape[0], _dp(d_polys),
+                                              _dp(d_polyaux), d_polys.shape[0], _dp(d_polyverts),
+                                              d_polyverts.shape[0], render_type, log_focus, force_linear, max_edges))
+
+    def submit_scene(self, sc: Scene):
+        for h, (tex, lg) in enumerate(sc.textures):
+            self.texture_upload(h, tex, lg)
+        me = int(sc.polys[:, 2].max()) if sc.n_polys else 0
+        self.submit_object(sc.verts, sc.polys, sc.polyverts, sc.render_type, sc.log_focus, polyaux=sc.polyaux,
+                           matrix=sc.matrix, force_linear=sc.force_linear, max_edges=min(max(me, 1), 15))
+
+    def submit_screen_polys(self, kind, polys):
+        """polys: list of (length, tuples int32[length+1][dim], colour[, tex]) in draw order."""
+        dim = DIM[kind]
+        desc = np.zeros((len(polys), 4), np.int32)
+        chunks, first, me = [], 0, 1
+        for i, p in enumerate(polys):
+            length, t, colour = p[0], _i32(p[1]).reshape(-1, dim), p[2]
+            assert t.shape[0] == length + 1
+            desc[i] = (first, length, colour, p[3] if len(p) > 3 else 0)
+            chunks.append(t)
+            first += length + 1
+            me = max(me, length)
+        tup = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, dim), np.int32)
+        self._chk(self.L.lt_submit_screen_polys(self.h_ctx, kind, _p(tup), tup.shape[0], _p(desc), len(polys),
+                                                min(me, 15)))

@@ -1,0 +1,280 @@
+"""Synthetic scene generators for the polygon path (host side, numpy, deterministic).
+
+Scenes use the flat layout the C-ABI takes (include/lt_gpu.h):
+
+  verts      int32[nv][4]   object-space X Y Z (4th lane unused), T_LNG_VECTOR stride
+                            (reference Trans.h:27)
+  polys      int32[np][4]   {colour, texture handle or -1, no_edges, first}
+  polyaux    int32[np][4]   {m_red, m_green, m_blue, m_type | log_texture_space_size<<8} or None
+  polyverts  int32[*][6]    M_polygon.m_vertices records [Idx R G B Tx Ty]
+                            (reference Engine.h:204-207); polygon i owns records
+                            first .. first+no_edges, the closing vertex repeated
+
+All randomness is splitmix64 so that every consumer (reference build, CPU restatement,
+HIP path) sees identical integers.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+M_FLAT, M_SHADED, M_TEXTURED = 2, 4, 8          # reference Engine.h:81-83
+M_PLANNAR, M_QUAD_XY = 1, 4                     # reference Engine.h:190-193
+
+_MASK = (1 << 64) - 1
+
+
+def splitmix64(seed: int, n: int) -> np.ndarray:
+    """n successive outputs of splitmix64 started at `seed` (uint64)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed & _MASK) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+class Rng:
+    """Stream of bounded integers drawn from splitmix64 in a fixed order."""
+
+    def __init__(self, seed: int):
+        self.seed = seed & _MASK
+        self.k = 0
+
+    def raw(self, n: int) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            out = splitmix64((self.seed + self.k * 0x9E3779B97F4A7C15) & _MASK, n)
+        self.k += n
+        return out
+
+    def ints(self, lo: int, hi: int, n: int) -> np.ndarray:
+        """n integers uniform in [lo, hi] (inclusive), int64."""
+        span = np.uint64(hi - lo + 1)
+        return (self.raw(n) % span).astype(np.int64) + lo
+
+
+@dataclass
+class Scene:
+    width: int
+    height: int
+    log_focus: int
+    render_type: int
+    verts: np.ndarray
+    polys: np.ndarray
+    polyverts: np.ndarray
+    polyaux: Optional[np.ndarray] = None
+    textures: List[tuple] = field(default_factory=list)     # [(texels int32[2^log][2^log], log)]
+    matrix: Optional[np.ndarray] = None                      # int32[12]; None = identity
+    force_linear: int = 0
+    name: str = ""
+
+    @property
+    def n_polys(self) -> int:
+        return int(self.polys.shape[0])
+
+
+IDENTITY = np.array([32768, 0, 0, 0, 0, 32768, 0, 0, 0, 0, 32768, 0], dtype=np.int32)
+
+
+def make_texture(seed: int, log_size: int) -> np.ndarray:
+    n = 1 << (2 * log_size)
+    return (splitmix64(seed, n) & np.uint64(0x00FFFFFF)).astype(np.int32).reshape(1 << log_size, 1 << log_size)
+
+
+def _triangles(rng: Rng, n: int, w: int, h: int, lf: int, radius: int, cx_rng, cy_rng, z_rng,
+               cull: str, rgb_equal: bool = False, tex: bool = False, first_z_min: int = 0,
+               first_z_frac: int = 0):
+    """Common body of the triangle generators: unshared vertices, 4 records per triangle."""
+    cx = rng.ints(cx_rng[0], cx_rng[1], n)
+    cy = rng.ints(cy_rng[0], cy_rng[1], n)
+    zc = rng.ints(z_rng[0], z_rng[1], n)
+    ox = rng.ints(-radius, radius, 3 * n).reshape(n, 3)
+    oy = rng.ints(-radius, radius, 3 * n).reshape(n, 3)
+    dz = rng.ints(-16, 16, 3 * n).reshape(n, 3)
+    rgb = rng.ints(0, 255, 9 * n).reshape(n, 3, 3)
+    flip = rng.ints(0, 1, n)
+    txy = rng.ints(0, 1023, 6 * n).reshape(n, 3, 2)
+    force = rng.ints(0, 99, n)
+    zv = zc[:, None] + dz
+    if first_z_min:
+        # keep the first vertex at or beyond the linear/perspective mapper switch for
+        # first_z_frac percent of the triangles (reference EngBase.cpp:491-493)
+        sel = force < first_z_frac
+        zv[:, 0] = np.where(sel, np.maximum(zv[:, 0], first_z_min), zv[:, 0])
+    px = cx[:, None] + ox
+    py = cy[:, None] + oy
+    vx = ((px - w // 2) * zv) >> lf
+    vy = ((py - h // 2) * zv) >> lf
+    # winding: make the projected cross product negative (drawn), then flip per `cull`
+    cross = (px[:, 1] - px[:, 0]) * (py[:, 2] - py[:, 0]) - (py[:, 1] - py[:, 0]) * (px[:, 2] - px[:, 0])
+    swap = cross > 0
+    if cull == "random":
+        swap = swap ^ (flip == 1)
+    order = np.tile(np.array([0, 1, 2]), (n, 1))
+    order[swap] = np.array([0, 2, 1])
+    rows = np.arange(n)[:, None]
+    vx, vy, zv = vx[rows, order], vy[rows, order], zv[rows, order]
+    rgb = rgb[rows, order]
+    txy = txy[rows, order]
+    if rgb_equal:
+        rgb = np.repeat(rgb[:, :1, :], 3, axis=1)
+    verts = np.zeros((3 * n, 4), dtype=np.int32)
+    verts[:, 0] = vx.reshape(-1)
+    verts[:, 1] = vy.reshape(-1)
+    verts[:, 2] = zv.reshape(-1)
+    pv = np.zeros((n, 4, 6), dtype=np.int32)
+    idx = (np.arange(n)[:, None] * 3 + np.arange(3)[None, :])
+    pv[:, :3, 0] = idx
+    pv[:, :3, 1:4] = rgb
+    if tex:
+        pv[:, :3, 4:6] = txy
+    pv[:, 3, :] = pv[:, 0, :]
+    polys = np.zeros((n, 4), dtype=np.int32)
+    polys[:, 0] = 0x00FFFFFF
+    polys[:, 1] = 0 if tex else -1
+    polys[:, 2] = 3
+    polys[:, 3] = np.arange(n) * 4
+    return verts, polys, pv.reshape(-1, 6)
+
+
+def gen_c2(n_tris: int = 1_000_000, width: int = 1920, height: int = 1080, log_focus: int = 10,
+           radius: int = 8, seed: int = 0xC0FFEE02, cull: str = "random") -> Scene:
+    """Gouraud-shaded Z-buffered triangles: centres uniform over the screen plus a
+    32-pixel margin, depth 64..4095, vertices within +-radius pixels of the centre,
+    per-vertex RGB uniform in 0..255, white base colour, identity camera."""
+    rng = Rng(seed)
+    verts, polys, pv = _triangles(rng, n_tris, width, height, log_focus, radius,
+                                  (-32, width + 31), (-32, height + 31), (64, 4095), cull)
+    return Scene(width, height, log_focus, M_SHADED, verts, polys, pv, matrix=IDENTITY.copy(),
+                 name=f"c2-r{radius}-{n_tris}")
+
+
+def gen_c3(n_tris: int = 10_000_000, width: int = 3840, height: int = 2160, log_focus: int = 11,
+           radius: int = 8, seed: int = 0xC0FFEE03, equal_lights: bool = True,
+           lin_percent: int = 90, cull: str = "random") -> Scene:
+    """Texture-mapped triangles that exercise the view-volume, near-plane and screen
+    clippers: centres uniform over the screen plus a quarter-screen margin, depth
+    4..4095, one 256x256 texture, texture coordinates 0..1023.  `lin_percent` of the
+    triangles keep their first vertex at z >= 1024 so that they take the linear mapper.
+    equal_lights=True gives each triangle one light value for all three vertices."""
+    rng = Rng(seed)
+    verts, polys, pv = _triangles(rng, n_tris, width, height, log_focus, radius,
+                                  (-(width // 4), width + width // 4 - 1),
+                                  (-(height // 4), height + height // 4 - 1), (4, 4095), cull,
+                                  rgb_equal=equal_lights, tex=True, first_z_min=1024,
+                                  first_z_frac=lin_percent)
+    aux = np.zeros((n_tris, 4), dtype=np.int32)
+    aux[:, 3] = M_PLANNAR | (8 << 8)
+    return Scene(width, height, log_focus, M_TEXTURED, verts, polys, pv, polyaux=aux,
+                 textures=[(make_texture(seed ^ 0x7E47, 8), 8)], matrix=IDENTITY.copy(),
+                 name=f"c3-r{radius}-{n_tris}")
+
+
+def gen_fuzz_polys(n_polys: int, width: int, height: int, log_focus: int, seed: int,
+                   render_type: int = M_SHADED, max_edges: int = 6, textured: bool = False,
+                   equal_lights: bool = False, zrange=(12, 900)) -> Scene:
+    """Differential-test scene: convex-ish and irregular polygons of 3..max_edges
+    vertices, many straddling the screen border or the near plane, some degenerate
+    (repeated vertices, zero area, zero height), with shared vertices between
+    neighbouring polygons so that depth and ownership ties occur."""
+    rng = Rng(seed)
+    verts_l, polys_l, pv_l, aux_l = [], [], [], []
+    first = 0
+    nv = 0
+    prev_pts = None
+    for i in range(n_polys):
+        e = int(rng.ints(3, max_edges, 1)[0])
+        mode = int(rng.ints(0, 9, 1)[0])
+        zc = int(rng.ints(zrange[0], zrange[1], 1)[0]) if mode != 3 else int(rng.ints(2, 30, 1)[0])
+        rad = int(rng.ints(1, max(2, min(width, height) // 2), 1)[0])
+        if mode == 4:
+            rad = int(rng.ints(0, 3, 1)[0])
+        cxp = int(rng.ints(-width // 3, width + width // 3, 1)[0])
+        cyp = int(rng.ints(-height // 3, height + height // 3, 1)[0])
+        ang0 = rng.ints(0, 359, 1)[0]
+        pts = []
+        for k in range(e):
+            a = (ang0 + (360 * k) // e + int(rng.ints(-20, 20, 1)[0])) * np.pi / 180.0
+            rr = rad if mode != 5 else int(rng.ints(0, rad, 1)[0])
+            # clockwise on screen (y down) gives a negative cross product = drawn
+            px = cxp + int(round(rr * np.cos(a)))
+            py = cyp + int(round(rr * np.sin(a)))
+            zv = zc + int(rng.ints(-8, 8, 1)[0]) if mode != 3 else zc + int(rng.ints(-25, 25, 1)[0])
+            if mode == 6 and k > 0:
+                py = cyp                                            # zero height
+            pts.append((px, py, zv))
+        if mode == 7 and e > 3:
+            pts[2] = pts[1]                                         # repeated vertex
+        if mode == 8 and prev_pts is not None:
+            # share an edge (two screen points, same depth) with the previous polygon
+            pts[0], pts[1] = prev_pts[1], prev_pts[0]
+        prev_pts = list(pts)
+        if int(rng.ints(0, 3, 1)[0]) == 0:
+            pts = pts[::-1]                                         # back-facing
+        idxs = []
+        for (px, py, zv) in pts:
+            vx = ((px - width // 2) * zv) >> log_focus
+            vy = ((py - height // 2) * zv) >> log_focus
+            verts_l.append((vx, vy, zv, 0))
+            idxs.append(nv)
+            nv += 1
+        lights = rng.ints(0, 300, 3 * e).reshape(e, 3)
+        if equal_lights:
+            lights[:] = lights[0]
+        tx = rng.ints(-64, 1200, 2 * e).reshape(e, 2)
+        for k in range(e + 1):
+            kk = k % e
+            pv_l.append((idxs[kk], lights[kk, 0], lights[kk, 1], lights[kk, 2], tx[kk, 0], tx[kk, 1]))
+        col = int(rng.ints(0, 0xFFFFFF, 1)[0])
+        polys_l.append((col, 0 if textured else -1, e, first))
+        aux_l.append((int(rng.ints(0, 255, 1)[0]), int(rng.ints(0, 255, 1)[0]),
+                      int(rng.ints(0, 255, 1)[0]), M_PLANNAR | (8 << 8)))
+        first += e + 1
+    sc = Scene(width, height, log_focus, render_type,
+               np.array(verts_l, dtype=np.int32).reshape(-1, 4),
+               np.array(polys_l, dtype=np.int32).reshape(-1, 4),
+               np.array(pv_l, dtype=np.int32).reshape(-1, 6),
+               polyaux=np.array(aux_l, dtype=np.int32).reshape(-1, 4),
+               matrix=IDENTITY.copy(), name=f"fuzz-{seed:x}")
+    if textured:
+        sc.textures = [(make_texture(seed ^ 0x7E47, 6), 6)]
+    return sc
+
+
+def gen_screen_polys(n: int, width: int, height: int, seed: int, dim: int = 6, max_edges: int = 6,
+                     spread: int = 2):
+    """Already-projected closed polygons for the G_*_polygon level: a list of
+    (length, tuples int32[length+1][dim], colour).  Coordinates reach `spread` screen
+    sizes beyond the border so that both 2-D clippers run; depths cover the range the
+    perspective stage produces (-52428..0) and a little beyond."""
+    rng = Rng(seed)
+    out = []
+    for _ in range(n):
+        e = int(rng.ints(3, max_edges, 1)[0])
+        big = int(rng.ints(0, 3, 1)[0])
+        if big == 0:
+            cx = int(rng.ints(-width * spread // 2, width + width * spread // 2, 1)[0])
+            cy = int(rng.ints(-height * spread // 2, height + height * spread // 2, 1)[0])
+            rad = int(rng.ints(1, max(width, height), 1)[0])
+        else:
+            cx = int(rng.ints(-8, width + 8, 1)[0])
+            cy = int(rng.ints(-8, height + 8, 1)[0])
+            rad = int(rng.ints(0, 24, 1)[0])
+        t = np.zeros((e + 1, dim), dtype=np.int32)
+        for k in range(e):
+            t[k, 0] = cx + int(rng.ints(-rad, rad, 1)[0])
+            t[k, 1] = cy + int(rng.ints(-rad, rad, 1)[0])
+            t[k, 2] = int(rng.ints(-53000, 100, 1)[0])
+            for j in range(3, min(dim, 6)):
+                t[k, j] = int(rng.ints(0, 300, 1)[0]) << 16
+            for j in range(6, dim):
+                t[k, j] = int(rng.ints(-64, 1200, 1)[0]) << 16
+        t[e] = t[0]
+        out.append((e, t, int(rng.ints(0, 0xFFFFFF, 1)[0])))
+    return out
+
+
+def frame_digest(a: np.ndarray) -> str:
+    """Checksum of an int32 frame (little-endian bytes): blake2b-64, hex."""
+    import hashlib
+    return hashlib.blake2b(np.ascontiguousarray(a, dtype="<i4").tobytes(), digest_size=8).hexdigest()
