@@ -34,6 +34,10 @@ def lib():
         raise RuntimeError(
             f"{SO_PATH} is missing: build the HIP library first "
             "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    # torch ships its own HIP/HSA runtime under the same sonames as /opt/rocm.  Two
+    # runtimes in one process cannot both own the GPU, so torch is loaded first and the
+    # library then binds to the runtime that is already in the process.
+    import torch  # noqa: F401
     L = C.CDLL(SO_PATH)
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     L.lt_ctx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
