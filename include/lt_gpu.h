@@ -99,6 +99,14 @@ int lt_framebuffer(lt_ctx *ctx, int32_t **d_colour, int32_t **d_depth);
 int lt_get_counters(lt_ctx *ctx, lt_counters *out);   /* implies lt_flush */
 int lt_reset_counters(lt_ctx *ctx);
 
+/* Stage timing with HIP events on the context's stream (no counterpart in the
+ * reference, which has no timers): when on, every submit records events around its
+ * kernels.  lt_get_stage_ms implies lt_flush and returns, summed since the last call,
+ * the milliseconds of {transform, setup, scan, bin, fill} and the number of submits. */
+#define LT_STAGES 5
+int lt_set_profiling(lt_ctx *ctx, int on);
+int lt_get_stage_ms(lt_ctx *ctx, double ms[LT_STAGES], int *submits);
+
 /* m_texture_bytes / m_log_texture_size of struct M_texture (Engine.h:148-152): copies a
  * 2^log_size square of int32 texels to HBM under `handle` (0 .. LT_MAX_TEXTURES-1). */
 int lt_texture_upload(lt_ctx *ctx, int handle, const int32_t *texels, int log_size);
@@ -117,8 +125,9 @@ int lt_transform(lt_ctx *ctx, const int32_t m[12], const int32_t *d_from, int32_
  * tuples, view-volume test, near-plane clip, perspective, back-face cull, screen
  * clip, edge scan, span fill with depth test.  render_type is what M_init_rendering
  * set; log_focus what M_set_camera set; force_linear is M_force_linear_tmapping.
- * max_edges bounds no_edges over the batch (0 = 15).  Pointers are HOST memory; the
- * call copies them to the GPU and returns after enqueueing. */
+ * max_edges bounds no_edges over the batch (0 = 15).  m == NULL means the vertices are
+ * already in view space (the M_render_polygon level, EngBase.cpp:379).  Pointers are
+ * HOST memory; the call copies them to the GPU and returns after enqueueing. */
 int lt_submit_object(lt_ctx *ctx, const int32_t m[12],
                      const int32_t *verts, int nv,
                      const int32_t *polys, const int32_t *polyaux, int np,

@@ -42,7 +42,12 @@ struct lt_ctx {
     int tex_log_h[LT_MAX_TEXTURES] = {};
     const int **tex_ptr_d = nullptr;
     int *tex_log_d = nullptr;
-    bool order_warned = false;
+    // stage timing
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double stage_ms[LT_STAGES] = {};
+    int stage_submits = 0;
     std::string err;
 };
 
@@ -79,6 +84,34 @@ int ensure(lt_ctx *c, DevBuf &b, size_t bytes)
     return LT_OK;
 }
 
+// record an event on the stream (profiling only); events are pooled and reused
+int mark(lt_ctx *c)
+{
+    if (!c->profiling) return LT_OK;
+    if (c->ev_used == c->ev_pool.size()) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->ev_pool.push_back(e);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used++], c->stream));
+    return LT_OK;
+}
+
+// fold recorded events (groups of LT_STAGES+1 per submit) into stage_ms; stream must be idle
+int collect(lt_ctx *c)
+{
+    for (size_t i = 0; i + LT_STAGES < c->ev_used; i += LT_STAGES + 1) {
+        for (int k = 0; k < LT_STAGES; k++) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i + k], c->ev_pool[i + k + 1]));
+            c->stage_ms[k] += ms;
+        }
+        c->stage_submits++;
+    }
+    c->ev_used = 0;
+    return LT_OK;
+}
+
 int use_device(lt_ctx *c)
 {
     HIPCHK(c, hipSetDevice(c->device));
@@ -86,7 +119,7 @@ int use_device(lt_ctx *c)
 }
 
 // set-up -> scan -> bin -> fill for one batch whose polygon data is on the device
-int run_batch(lt_ctx *c, bool screen, int dim, const int *d_verts, int nv, const int *d_polys, const int *d_aux,
+int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_verts, int nv, const int *d_polys, const int *d_aux,
               int np, const int *d_pv, int npv, int render_type, int log_focus, int force_linear, int max_edges)
 {
     const int na = dim - 2;
@@ -105,8 +138,12 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int *d_verts, int nv, const
     if ((rc = ensure(c, c->tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
 
     HIPCHK(c, hipMemsetAsync(c->tcount.p, 0, (size_t)c->ntiles * sizeof(unsigned), c->stream));
+    if (screen) { if ((rc = mark(c))) return rc; if ((rc = mark(c))) return rc; }   // no transform stage
+    // (object mode: lt_submit_object_dev has recorded the marks around the transform)
 
     SetupArgs sa{};
+    sa.use_matrix = m ? 1 : 0;
+    if (m) for (int i = 0; i < 12; i++) sa.m[i] = m[i];
     sa.verts = d_verts; sa.polys = d_polys; sa.polyaux = d_aux; sa.polyverts = d_pv;
     sa.np = np; sa.nv = nv; sa.npv = npv;
     sa.render_type = render_type; sa.log_focus = log_focus; sa.force_linear = force_linear;
@@ -116,11 +153,14 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int *d_verts, int nv, const
     sa.hdr = (PrimHdr *)c->hdr.p; sa.edges = (int *)c->edges.p;
     sa.tile_count = (unsigned *)c->tcount.p; sa.status = c->status;
     launch_setup(c->stream, dim, screen, sa);
+    if ((rc = mark(c))) return rc;
 
     launch_scan(c->stream, (const unsigned *)c->tcount.p, (unsigned *)c->toffset.p, (unsigned *)c->tcursor.p,
                 c->ntiles, capacity, c->status);
+    if ((rc = mark(c))) return rc;
     launch_bin(c->stream, (const PrimHdr *)c->hdr.p, np, c->tiles_x, (const unsigned *)c->toffset.p,
                (unsigned *)c->tcursor.p, (unsigned *)c->list.p, capacity, c->status);
+    if ((rc = mark(c))) return rc;
 
     RasterArgs ra{};
     ra.hdr = (const PrimHdr *)c->hdr.p; ra.edges = (const int *)c->edges.p;
@@ -133,6 +173,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int *d_verts, int nv, const
     ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
     ra.status = c->status;
     launch_raster(c->stream, na, ra);
+    if ((rc = mark(c))) return rc;
     HIPCHK(c, hipGetLastError());
 
     c->clear_pending = false;
@@ -208,6 +249,7 @@ int lt_ctx_destroy(lt_ctx *c)
         if (c->tex_data[i]) (void)hipFree(c->tex_data[i]);
     if (c->cbuf) (void)hipFree(c->cbuf);
     if (c->zbuf) (void)hipFree(c->zbuf);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->status) (void)hipFree(c->status);
     if (c->tex_ptr_d) (void)hipFree((void *)c->tex_ptr_d);
     if (c->tex_log_d) (void)hipFree(c->tex_log_d);
@@ -260,6 +302,7 @@ int lt_flush(lt_ctx *c)
     if (rc) return rc;
     if ((rc = materialize_clear(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = collect(c))) return rc;
     Status s;
     HIPCHK(c, hipMemcpy(&s, c->status, sizeof s, hipMemcpyDeviceToHost));
     if (s.list_overflow > c->base.list_overflow) {
@@ -341,6 +384,27 @@ int lt_reset_counters(lt_ctx *c)
     return LT_OK;
 }
 
+int lt_set_profiling(lt_ctx *c, int on)
+{
+    if (!c) return LT_ERR_ARG;
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = collect(c))) return rc;
+    c->profiling = on != 0;
+    return LT_OK;
+}
+
+int lt_get_stage_ms(lt_ctx *c, double ms[LT_STAGES], int *submits)
+{
+    if (!c || !ms) return LT_ERR_ARG;
+    int rc = lt_flush(c);
+    for (int k = 0; k < LT_STAGES; k++) { ms[k] = c->stage_ms[k]; c->stage_ms[k] = 0; }
+    if (submits) *submits = c->stage_submits;
+    c->stage_submits = 0;
+    return rc;
+}
+
 int lt_texture_upload(lt_ctx *c, int handle, const int32_t *texels, int log_size)
 {
     if (!c || !texels) return LT_ERR_ARG;
@@ -376,16 +440,17 @@ int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts,
     if (!c) return LT_ERR_ARG;
     int dim = 0, rc;
     if ((rc = check_type(c, render_type, &dim))) return rc;
-    if (np < 0 || nv < 0 || npv < 0 || !m) return fail(c, LT_ERR_ARG, "lt_submit_object: negative count or NULL matrix");
+    if (np < 0 || nv < 0 || npv < 0) return fail(c, LT_ERR_ARG, "lt_submit_object: negative count");
     if (np == 0) return LT_OK;
     if (!d_verts || !d_polys || !d_polyverts) return fail(c, LT_ERR_ARG, "lt_submit_object: NULL array");
     if (render_type == LT_FLAT && !d_polyaux) return fail(c, LT_ERR_ARG, "lt_submit_object: LT_FLAT needs polyaux (m_red, m_green, m_blue)");
     if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_submit_object: log_focus %d outside 0..30", log_focus);
     if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
     if ((rc = use_device(c))) return rc;
-    if ((rc = ensure(c, c->view, (size_t)nv * 4 * sizeof(int)))) return rc;
-    launch_transform(c->stream, m, d_verts, (int *)c->view.p, nv);
-    return run_batch(c, false, dim, (const int *)c->view.p, nv, d_polys, d_polyaux, np, d_polyverts, npv, render_type,
+    // the transform is applied inside the setup kernel: its stage time is part of "setup"
+    if ((rc = mark(c))) return rc;
+    if ((rc = mark(c))) return rc;
+    return run_batch(c, false, dim, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts, npv, render_type,
                      log_focus, force_linear, max_edges);
 }
 
@@ -429,7 +494,7 @@ int lt_submit_screen_polys(lt_ctx *c, int kind, const int32_t *tuples, int ntupl
     HIPCHK(c, hipMemcpyAsync(c->s_polys.p, desc, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->s_pv.p, tuples, (size_t)ntuples * dim * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return run_batch(c, true, dim, nullptr, 0, (const int *)c->s_polys.p, nullptr, n, (const int *)c->s_pv.p, ntuples,
+    return run_batch(c, true, dim, nullptr, nullptr, 0, (const int *)c->s_polys.p, nullptr, n, (const int *)c->s_pv.p, ntuples,
                      kind, 0, 0, max_edges);
 }
 

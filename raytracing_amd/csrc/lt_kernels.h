@@ -38,7 +38,9 @@ struct Status {
 };
 
 struct SetupArgs {
-    const int *verts;        // view-space int32[nv][4]      (object mode)
+    int m[12];               // concatenated transform, applied while vertices are read
+    int use_matrix;          // 0: verts are already in view space
+    const int *verts;        // int32[nv][4]                  (object mode)
     const int *polys;        // int32[np][4]                  (object mode) / desc (screen mode)
     const int *polyaux;      // int32[np][4] or null
     const int *polyverts;    // int32[*][6]                   (object mode) / tuples (screen mode)

@@ -45,6 +45,17 @@ struct Tup {
     int v[DIM];
 };
 
+// element-wise select: keeps tuples in registers (a ?: on the structs themselves is
+// compiled as a select between two stack addresses)
+template <int DIM>
+__device__ __forceinline__ Tup<DIM> sel(bool c, const Tup<DIM> &a, const Tup<DIM> &b)
+{
+    Tup<DIM> r;
+#pragma unroll
+    for (int i = 0; i < DIM; i++) r.v[i] = c ? a.v[i] : b.v[i];
+    return r;
+}
+
 // ------------------------------------------------------------------ transform
 
 struct Mat12 {
@@ -71,6 +82,23 @@ __global__ void __launch_bounds__(256) transform_kernel(Mat12 M, const int4 *__r
     d[2] = o[2];
 }
 
+// The same transform applied to one vertex as the setup kernel reads it, so that an
+// object's view-space vertices never make a round trip through HBM.
+__device__ __forceinline__ int4 load_vertex(const SetupArgs &a, int idx)
+{
+    int4 p = ((const int4 *)a.verts)[idx];
+    if (a.use_matrix) {
+        int o[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            o[r] = wadd(wadd(wadd(wmul(a.m[4 * r], p.x) >> 15, wmul(a.m[4 * r + 1], p.y) >> 15),
+                             wmul(a.m[4 * r + 2], p.z) >> 15),
+                        a.m[4 * r + 3]);
+        p.x = o[0]; p.y = o[1]; p.z = o[2];
+    }
+    return p;
+}
+
 // ------------------------------------------------------------------ clipping
 
 template <int DIM>
@@ -90,7 +118,7 @@ __device__ __forceinline__ bool clip_line(const Tup<DIM> &v1, const Tup<DIM> &v2
                                           Tup<DIM> &o1, Tup<DIM> &o2, bool &moved, bool &bad)
 {
     bool swap = !(v1.v[AX] < v2.v[AX]);
-    Tup<DIM> lo = swap ? v2 : v1, hi = swap ? v1 : v2;
+    Tup<DIM> lo = sel(swap, v2, v1), hi = sel(swap, v1, v2);
     moved = false;
     if (BOTH) {
         if (lo.v[AX] >= bmax || hi.v[AX] <= bmin) return false;
@@ -102,7 +130,8 @@ __device__ __forceinline__ bool clip_line(const Tup<DIM> &v1, const Tup<DIM> &v2
         bool whereto = true;
         int guard = 0;
         while (m.v[AX] != bmin) {
-            if (whereto) l = m; else r = m;
+            l = sel(whereto, m, l);
+            r = sel(whereto, r, m);
             midpoint(m, l, r);
             whereto = m.v[AX] < bmin;
             if (++guard > 40) { bad = true; break; }
@@ -115,7 +144,8 @@ __device__ __forceinline__ bool clip_line(const Tup<DIM> &v1, const Tup<DIM> &v2
         bool whereto = false;
         int guard = 0;
         while (m.v[AX] != bmax) {
-            if (whereto) l = m; else r = m;
+            l = sel(whereto, m, l);
+            r = sel(whereto, r, m);
             midpoint(m, l, r);
             whereto = m.v[AX] < bmax;
             if (++guard > 40) { bad = true; break; }
@@ -123,8 +153,8 @@ __device__ __forceinline__ bool clip_line(const Tup<DIM> &v1, const Tup<DIM> &v2
         hi = m;
         moved = moved || swap;
     }
-    o1 = swap ? hi : lo;
-    o2 = swap ? lo : hi;
+    o1 = sel(swap, hi, lo);
+    o2 = sel(swap, lo, hi);
     return true;
 }
 
@@ -192,7 +222,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
         for (int i = 0; i <= e; i++) {
             int idx = a.polyverts[(size_t)(first + i) * 6];
             if ((unsigned)idx >= (unsigned)a.nv) { bad = true; go = false; break; }
-            int4 p = ((const int4 *)a.verts)[idx];
+            int4 p = load_vertex(a, idx);
             mn[0] = min(mn[0], p.x); mx[0] = max(mx[0], p.x);
             mn[1] = min(mn[1], p.y); mx[1] = max(mx[1], p.y);
             mn[2] = min(mn[2], p.z); mx[2] = max(mx[2], p.z);
@@ -221,10 +251,9 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     // of a z-clipped polygon.  screen mode: iterations 0..e read the tuples.
     const int iters = SCREEN ? e + 1 : e + 2;
     for (int it = 0; go && it < iters; it++) {
-        Tup<DIM> zout[2];
-        bool zclosing[2] = {false, false};
+        Tup<DIM> zo0 = zprev, zo1 = zprev;      // up to two tuples leave the Z stage per step
+        bool zclosing0 = false;
         int cz = 0;
-        zout[0] = zprev; zout[1] = zprev;
 
         if (it <= e) {
             Tup<DIM> t;
@@ -232,11 +261,11 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                 const int *src = a.polyverts + (size_t)(first + it) * DIM;
 #pragma unroll
                 for (int j = 0; j < DIM; j++) t.v[j] = src[j];
-                zout[0] = t; zclosing[0] = (it == e); cz = 1;
+                zo0 = t; zclosing0 = (it == e); cz = 1;
             } else {
                 // CI_construct_tuples, EngBase.cpp:58-137
                 const int *rec = a.polyverts + (size_t)(first + it) * 6;
-                int4 p = ((const int4 *)a.verts)[rec[0]];
+                int4 p = load_vertex(a, rec[0]);
                 t.v[0] = p.x; t.v[1] = p.y; t.v[2] = p.z;
                 if (DIM >= 6) { t.v[3] = wshl(rec[1], 16); t.v[4] = wshl(rec[2], 16); t.v[5] = wshl(rec[3], 16); }
                 if (DIM == 8) {
@@ -245,26 +274,27 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                     t.v[DIM - 1] = tx ? wshl(rec[5], 16) : 0;
                 }
                 if (!zclip) {
-                    zout[0] = t; zclosing[0] = (it == e); cz = 1;
+                    zo0 = t; zclosing0 = (it == e); cz = 1;
                 } else if (it > 0) {
                     // C_polygon_z_clipping, Clipp3D.cpp:137-155
                     Tup<DIM> o1, o2;
                     bool moved;
                     if (clip_line<DIM, 2, false>(zprev, t, 10, 0, o1, o2, moved, bad)) {
-                        if (moved) { zout[0] = o1; zout[1] = o2; cz = 2; }
-                        else       { zout[0] = o2; cz = 1; }
+                        zo0 = sel(moved, o1, o2);
+                        zo1 = o2;
+                        cz = moved ? 2 : 1;
                     }
                 }
                 zprev = t;
             }
         } else if (zclip) {
             // closing tuple of the z-clipped polygon = its first tuple (Clipp3D.cpp:156)
-            if (zn > 0) { zout[0] = zfirst; zclosing[0] = true; cz = 1; }
+            if (zn > 0) { zo0 = zfirst; zclosing0 = true; cz = 1; }
         }
 
         for (int k = 0; k < cz; k++) {
-            Tup<DIM> p = k ? zout[1] : zout[0];
-            bool closing = k ? zclosing[1] : zclosing[0];
+            Tup<DIM> p = sel(k != 0, zo1, zo0);
+            bool closing = k == 0 && zclosing0;
             if (!SCREEN) {
                 if (!closing) {
                     if (zn == 0) { zfirst = p; first_view_z = p.v[2]; }
@@ -285,15 +315,15 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                 }
             }
             // ---- X stage: C_polygon_x_clipping, Clipp2D.cpp:253-272
-            Tup<DIM> xout[2];
-            xout[0] = p; xout[1] = p;
+            Tup<DIM> xo0 = p, xo1 = p;
             int cx = 0;
             if (xn > 0) {
                 Tup<DIM> o1, o2;
                 bool moved;
                 if (clip_line<DIM, 0, true>(xprev, p, 0, wx, o1, o2, moved, bad)) {
-                    if (moved) { xout[0] = o1; xout[1] = o2; cx = 2; }
-                    else       { xout[0] = o2; cx = 1; }
+                    xo0 = sel(moved, o1, o2);
+                    xo1 = o2;
+                    cx = moved ? 2 : 1;
                 }
             }
             xprev = p;
@@ -303,7 +333,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
             const int cs = cx + (closing ? 1 : 0);
             for (int j = 0; j < cs; j++) {
                 bool sclosing = j >= cx;
-                Tup<DIM> s = sclosing ? sfirst : (j ? xout[1] : xout[0]);
+                Tup<DIM> s = sel(sclosing, sfirst, sel(j != 0, xo1, xo0));
                 if (sclosing && sn == 0) break;
                 if (!sclosing) {
                     minx = min(minx, s.v[0]); maxx = max(maxx, s.v[0]);

@@ -90,6 +90,16 @@ class Context:
     def reset_counters(self):
         self._chk(self.L.lt_reset_counters(self.h_ctx))
 
+    def set_profiling(self, on):
+        self._chk(self.L.lt_set_profiling(self.h_ctx, int(on)))
+
+    def stage_ms(self):
+        """-> ({stage: ms summed since the last call}, submits)"""
+        arr = (C.c_double * 5)()
+        n = C.c_int(0)
+        self._chk(self.L.lt_get_stage_ms(self.h_ctx, C.byref(arr), C.byref(n)))
+        return dict(zip(("transform", "setup", "scan", "bin", "fill"), list(arr))), n.value
+
     def texture_upload(self, handle, texels, log_size):
         t = _i32(texels).reshape(-1)
         assert t.size == 1 << (2 * log_size)
