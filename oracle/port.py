@@ -187,8 +187,8 @@ def trig_tables(variant=0):
 def make_matrix(cam=(0, 0, 0, 0, 0, 0), obj=(0, 0, 0, 0, 0, 0), variant=0):
     """cam = (alp, bet, gam, x, y, z); obj = (alp, bet, gam, x, y, z) -> int32[12]."""
     m = np.zeros(12, np.int32)
-    lib().lto_make_matrix(variant, cam[0], cam[1], cam[2], cam[3], cam[4], cam[5],
-                          obj[0], obj[1], obj[2], obj[3], obj[4], obj[5], _p(m))
+    lib().lto_make_matrix(variant, *[int(v) for v in cam],
+                          *[int(v) for v in obj], _p(m))
     return m
 
 

@@ -91,8 +91,8 @@ class Ref:
 
     def make_matrix(self, cam=(0, 0, 0, 0, 0, 0), obj=(0, 0, 0, 0, 0, 0), log_focus=8):
         m = np.zeros(12, np.int32)
-        self.L.ltref_make_matrix(cam[0], cam[1], cam[2], cam[3], cam[4], cam[5], log_focus,
-                                 obj[0], obj[1], obj[2], obj[3], obj[4], obj[5], _p(m))
+        self.L.ltref_make_matrix(*[int(v) for v in cam], log_focus,
+                                 *[int(v) for v in obj], _p(m))
         return m
 
     def transform(self, m12, verts):

@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by RUNNING THE REFERENCE'S OWN CODE.
+
+Runs only where /root/reference is present (the build container): it loads the checker
+libraries that oracle/build_ref.sh compiles from the reference sources and records, for
+fixed seeded inputs, what the reference computes.  The outputs are data only -- inputs
+and expected outputs -- stored as .npz (no pickles) and .json next to this script:
+
+  stage_kats.npz    per-stage known answers (transform, perspective, clippers, edge scan
+                    row tables, CL_light)
+  frames.json       per-scene digests of the colour and depth buffers + fragment-free
+                    metadata; scenes are regenerated from seeds by raytracing_amd.scenes
+  c1_scene.npz      configuration 1: the tracer.dat world (quad + three spheres, tessellated
+                    and lit by this script) as flat scene arrays, with the reference's frame
+  crops.npz         a few raw 32x32 crops of reference frames
+
+Usage:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import oracle.ref as R  # noqa: E402
+from raytracing_amd import scenes as S  # noqa: E402
+
+REFDIR = "/root/reference"
+
+
+# ----------------------------------------------------------------------------- frames
+
+def frame_cases():
+    """(name, scene factory, clear tuple) -- shared with the tests through frames.json keys."""
+    cases = []
+    for seed in range(6):
+        for rt in (S.M_FLAT, S.M_SHADED, S.M_TEXTURED):
+            cases.append((f"fuzz160x120-rt{rt}-s{seed}",
+                          dict(gen="fuzz", n=70, w=160, h=120, lf=7, seed=1000 + seed * 7 + rt, rt=rt,
+                               textured=rt == S.M_TEXTURED, equal_lights=False)))
+    for seed in range(4):
+        cases.append((f"fuzzlin160x120-s{seed}",
+                      dict(gen="fuzzlin", n=70, w=160, h=120, lf=7, seed=2000 + seed)))
+    cases.append(("c2small-640x480-20k", dict(gen="c2", n=20000, w=640, h=480, lf=9, radius=8, seed=0xC0FFEE02)))
+    cases.append(("c2large-640x480-2k", dict(gen="c2", n=2000, w=640, h=480, lf=9, radius=96, seed=0xC0FFEE12)))
+    cases.append(("c2small-1920x1080-50k", dict(gen="c2", n=50000, w=1920, h=1080, lf=10, radius=8, seed=0xC0FFEE02)))
+    cases.append(("c3lin-640x480-20k", dict(gen="c3", n=20000, w=640, h=480, lf=9, radius=10, seed=0xC0FFEE03,
+                                            equal_lights=True, lin_percent=100)))
+    cases.append(("c3mix-640x480-20k", dict(gen="c3", n=20000, w=640, h=480, lf=9, radius=10, seed=0xC0FFEE03,
+                                            equal_lights=True, lin_percent=90)))
+    cases.append(("c3q2-640x480-5k", dict(gen="c3", n=5000, w=640, h=480, lf=9, radius=10, seed=0xC0FFEE33,
+                                          equal_lights=False, lin_percent=100)))
+    return cases
+
+
+def build_scene(spec):
+    g = spec["gen"]
+    if g == "fuzz":
+        return S.gen_fuzz_polys(spec["n"], spec["w"], spec["h"], spec["lf"], spec["seed"], render_type=spec["rt"],
+                                textured=spec["textured"], equal_lights=spec["equal_lights"])
+    if g == "fuzzlin":
+        sc = S.gen_fuzz_polys(spec["n"], spec["w"], spec["h"], spec["lf"], spec["seed"], render_type=S.M_TEXTURED,
+                              textured=True, equal_lights=True, zrange=(1100, 3000))
+        return sc
+    if g == "c2":
+        return S.gen_c2(spec["n"], spec["w"], spec["h"], spec["lf"], radius=spec["radius"], seed=spec["seed"])
+    if g == "c3":
+        return S.gen_c3(spec["n"], spec["w"], spec["h"], spec["lf"], radius=spec["radius"], seed=spec["seed"],
+                        equal_lights=spec["equal_lights"], lin_percent=spec["lin_percent"])
+    raise ValueError(g)
+
+
+CLEAR = (0x102030, 255, 255, 255)
+
+
+def render_ref(sc):
+    ref = R.Ref(sc.width, sc.height)
+    for h, (tex, lg) in enumerate(sc.textures):
+        ref.set_texture(h, tex, lg)
+    ref.clear(*CLEAR)
+    vv = ref.transform(sc.matrix, sc.verts)
+    ref.render_polys(vv, sc.polys, sc.polyaux, sc.polyverts, sc.render_type, sc.log_focus, sc.force_linear)
+    return ref.cbuf().copy(), ref.zbuf().copy()
+
+
+# ----------------------------------------------------------------------------- stage KATs
+
+def stage_kats():
+    ref = R.Ref(160, 120)
+    out = {}
+    rng = S.Rng(4242)
+    # trig tables: both variants of T_init_math
+    s, c = ref.trig_tables()
+    out["trig_sin_trans"], out["trig_cos_trans"] = s, c
+    s2, c2 = R.Ref(160, 120, "transbs").trig_tables()
+    out["trig_sin_transbs"], out["trig_cos_transbs"] = s2, c2
+    # matrices + transform
+    cams = rng.ints(0, 255, 3 * 8).reshape(8, 3)
+    camp = rng.ints(-500, 500, 3 * 8).reshape(8, 3)
+    obja = rng.ints(0, 255, 3 * 8).reshape(8, 3)
+    objp = rng.ints(-2000, 2000, 3 * 8).reshape(8, 3)
+    mats = []
+    for i in range(8):
+        mats.append(ref.make_matrix(tuple(cams[i]) + tuple(camp[i]), tuple(obja[i]) + tuple(objp[i]), 8))
+    out["mat_cam"] = np.concatenate([cams, camp], axis=1).astype(np.int32)
+    out["mat_obj"] = np.concatenate([obja, objp], axis=1).astype(np.int32)
+    out["mat_m12"] = np.array(mats, dtype=np.int32)
+    v = rng.ints(-70000, 70000, 4 * 256).reshape(-1, 4).astype(np.int32)
+    out["xf_in"] = v
+    out["xf_out"] = np.array([ref.transform(m, v) for m in mats], dtype=np.int32)
+    # perspective
+    t = np.zeros((200, 8), np.int32)
+    t[:, 0] = rng.ints(-300000, 300000, 200)
+    t[:, 1] = rng.ints(-300000, 300000, 200)
+    t[:, 2] = rng.ints(10, 60000, 200)
+    t[:100, 0] = rng.ints(-(2 ** 31) + 1, 2 ** 31 - 1, 100)       # needs the 64-bit quotient
+    t[:, 3:] = rng.ints(-(2 ** 31), 2 ** 31 - 1, 200 * 5).reshape(200, 5)
+    out["persp_in"] = t
+    out["persp_out_lf8"] = ref.perspective(t, 8, 8)
+    out["persp_out_lf11"] = ref.perspective(t, 8, 11)
+    # volume clipping
+    mn = rng.ints(-3000, 3000, 3 * 300).reshape(-1, 3).astype(np.int32)
+    ext = rng.ints(0, 3000, 3 * 300).reshape(-1, 3).astype(np.int32)
+    mx = mn + ext
+    mn[:40, 2] = rng.ints(-5, 15, 40)
+    mx[:40, 2] = mn[:40, 2] + rng.ints(0, 6, 40)
+    out["vol_min"], out["vol_max"] = mn, mx
+    out["vol_out"] = np.array([ref.volume_clipping(mn[i], mx[i]) for i in range(300)], np.int32)
+    # back-face test
+    tri = rng.ints(-40000, 40000, 6 * 300).reshape(-1, 3, 2).astype(np.int32)
+    tri[:20, 2] = tri[:20, 0]                                      # degenerate: zero area
+    out["cull_in"] = tri
+    out["cull_out"] = np.array([ref.normal_z_negative(tri[i, 0], tri[i, 1], tri[i, 2]) for i in range(300)], np.int32)
+    # line clippers: axis 0 (x, bounds 0..159), 1 (y, 0..119), 2 (z, >=10)
+    for axis, name in ((0, "x"), (1, "y"), (2, "z")):
+        a = rng.ints(-400, 600, 8 * 400).reshape(-1, 8).astype(np.int32)
+        b = rng.ints(-400, 600, 8 * 400).reshape(-1, 8).astype(np.int32)
+        a[:, 3:] = rng.ints(-(2 ** 24), 2 ** 24, 5 * 400).reshape(-1, 5)
+        b[:, 3:] = rng.ints(-(2 ** 24), 2 ** 24, 5 * 400).reshape(-1, 5)
+        # exact-bound and equal-coordinate cases
+        bound_lo = 10 if axis == 2 else 0
+        bound_hi = {0: 159, 1: 119, 2: 0}[axis]
+        a[:30, axis] = bound_lo
+        b[30:60, axis] = bound_hi
+        b[60:80, axis] = a[60:80, axis]
+        a[80:100, axis] = bound_lo - 1
+        b[100:120, axis] = bound_hi + 1
+        res = np.zeros((400, 2 + 16), np.int32)
+        for i in range(400):
+            r, o1, o2, moved = ref.line_clipping(axis, a[i], b[i])
+            res[i, 0], res[i, 1] = r, moved
+            if r:
+                res[i, 2:10], res[i, 10:18] = o1, o2
+        out[f"line{name}_a"], out[f"line{name}_b"], out[f"line{name}_out"] = a, b, res
+    # polygon clippers + edge scan row tables on random closed polygons (dim 6)
+    polys = S.gen_screen_polys(60, 160, 120, seed=77, dim=6, max_edges=6)
+    pin, pn, pout, pon = [], [], [], []
+    scan = []
+    for (e, t, col) in polys:
+        n, o = ref.polygon_clipping(0, t, 6)
+        pad = np.zeros((17, 6), np.int32)
+        pad[: e + 1] = t
+        pin.append(pad)
+        pn.append(e)
+        po = np.zeros((17, 6), np.int32)
+        po[: min(n + 1, 17)] = o[: min(n + 1, 17)]
+        pout.append(po)
+        pon.append(n)
+        miny, maxy, xs, xe, vs, ve = ref.scan_polygon(t, 6)
+        scan.append(np.concatenate([[miny, maxy], xs, xe, vs[:, :4].reshape(-1), ve[:, :4].reshape(-1)]).astype(np.int64))
+    out["polyx_in"], out["polyx_n"] = np.array(pin), np.array(pn, np.int32)
+    out["polyx_out"], out["polyx_on"] = np.array(pout), np.array(pon, np.int32)
+    out["scan_tables"] = np.array(scan, dtype=np.int64)
+    # z polygon clipper on view-space polygons (dim 6)
+    zin, zn, zout, zon = [], [], [], []
+    for i in range(60):
+        e = int(rng.ints(3, 6, 1)[0])
+        t = np.zeros((e + 1, 6), np.int32)
+        t[:e, 0] = rng.ints(-500, 500, e)
+        t[:e, 1] = rng.ints(-500, 500, e)
+        t[:e, 2] = rng.ints(-40, 80, e)
+        t[:e, 3:] = rng.ints(0, 255 << 16, 3 * e).reshape(e, 3)
+        t[e] = t[0]
+        n, o = ref.polygon_clipping(2, t, 6)
+        pad = np.zeros((17, 6), np.int32)
+        pad[: e + 1] = t
+        zin.append(pad)
+        zn.append(e)
+        po = np.zeros((17, 6), np.int32)
+        po[: min(n + 1, 17)] = o[: min(n + 1, 17)]
+        zout.append(po)
+        zon.append(n)
+    out["polyz_in"], out["polyz_n"] = np.array(zin), np.array(zn, np.int32)
+    out["polyz_out"], out["polyz_on"] = np.array(zout), np.array(zon, np.int32)
+    # CL_light / CL_colour
+    cl = rng.ints(0, 0xFFFFFF, 500).astype(np.int32)
+    lr = rng.ints(0, 400, 3 * 500).reshape(-1, 3).astype(np.int32)
+    out["cl_in_colour"], out["cl_in_light"] = cl, lr
+    out["cl_light_out"] = np.array([ref.cl_light(int(cl[i]), *map(int, lr[i])) for i in range(500)], np.int32)
+    out["cl_colour_out"] = np.array([ref.cl_colour(*map(int, lr[i])) for i in range(500)], np.int32)
+    return out
+
+
+# ----------------------------------------------------------------------------- configuration 1
+
+def parse_tracer_dat(path):
+    """The few numbers of the reference's tracer.dat world: lights, spheres, one polygon."""
+    txt = open(path).read()
+    num = r"[-+]?\d*\.?\d+"
+    lights = [tuple(map(float, m)) for m in re.findall(
+        rf"var light \w+ \{{\[({num}) ({num}) ({num})\] \[({num}) ({num}) ({num})\]\}}", txt)]
+    spheres = [tuple(map(float, m)) for m in re.findall(
+        rf"var sphere \w+ \{{ \d+ \{{\[({num}) ({num}) ({num})\].*?\}}\s*\[\s*({num})\s+({num})\s+({num})\]\s*({num})\s*\}}", txt)]
+    vrt = re.search(r"var \[15\]float vrt \[(.*?)\]", txt, re.S).group(1).split()
+    quad = np.array(list(map(float, vrt)), dtype=np.float64).reshape(5, 3)
+    pcol = tuple(map(float, re.search(rf"var polygon \w+\s+\{{ \d+ \{{\[({num}) ({num}) ({num})\]", txt).groups()))
+    return lights, spheres, quad, pcol
+
+
+def c1_scene():
+    """tracer.dat as polygon objects: the quad and three lat/long spheres (32 x 16),
+    vertex light from the two point lights (Lambert, ambient 0.1), M_SHADED, 640x480."""
+    lights, spheres, quad, pcol = parse_tracer_dat(os.path.join(REFDIR, "tracer.dat"))
+    objs = []
+
+    def shade(p, n):
+        tot = 0.1
+        for (lx, ly, lz, ir, ig, ib) in lights:
+            d = np.array([lx, ly, lz]) - p
+            d = d / np.linalg.norm(d)
+            tot += max(0.0, float(np.dot(d, n))) * ir
+        return int(min(255, max(0, round(255 * tot))))
+
+    # quad (closed list of 5 vertices in the file; 4 edges)
+    qn = np.array([0.0, -1.0, 0.0])
+    verts = [(int(x), int(y), int(z), 0) for (x, y, z) in quad[:4]]
+    recs = []
+    for k in [0, 1, 2, 3, 0]:
+        l = shade(quad[k], qn)
+        recs.append((k, l, l, l, 0, 0))
+    colour = (int(pcol[0] * 255) << 16) | (int(pcol[1] * 255) << 8) | int(pcol[2] * 255)
+    # both windings so that one of them faces the camera
+    polys = [(colour, -1, 4, 0), (colour, -1, 4, 5)]
+    recs2 = [recs[0], recs[3], recs[2], recs[1], recs[0]]
+    objs.append(dict(verts=np.array(verts, np.int32), polys=np.array(polys, np.int32),
+                     polyverts=np.array(recs + recs2, np.int32)))
+    # spheres
+    NLON, NLAT = 32, 16
+    for (cr, cg, cb, cx, cy, cz, rad) in spheres:
+        colour = (min(255, int(cr * 255)) << 16) | (min(255, int(cg * 255)) << 8) | min(255, int(cb * 255))
+        vs, light = [], []
+
+        def add(theta, phi):
+            n = np.array([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)])
+            p = np.array([cx, cy, cz]) + rad * n
+            vs.append((int(round(p[0])), int(round(p[1])), int(round(p[2])), 0))
+            light.append(shade(p, n))
+            return len(vs) - 1
+
+        top = add(0.0, 0.0)
+        rings = [[add(np.pi * i / NLAT, 2 * np.pi * j / NLON) for j in range(NLON)] for i in range(1, NLAT)]
+        bot = add(np.pi, 0.0)
+        tris = []
+        for j in range(NLON):
+            j2 = (j + 1) % NLON
+            tris.append((top, rings[0][j2], rings[0][j]))
+            tris.append((bot, rings[-1][j], rings[-1][j2]))
+            for i in range(NLAT - 2):
+                a, b, c, d = rings[i][j], rings[i][j2], rings[i + 1][j], rings[i + 1][j2]
+                tris.append((a, b, d))
+                tris.append((a, d, c))
+        recs, polys = [], []
+        for (a, b, c) in tris:
+            polys.append((colour, -1, 3, len(recs)))
+            for k in (a, b, c, a):
+                recs.append((k, light[k], light[k], light[k], 0, 0))
+        objs.append(dict(verts=np.array(vs, np.int32), polys=np.array(polys, np.int32),
+                         polyverts=np.array(recs, np.int32)))
+    return objs
+
+
+def c1_golden():
+    W, H, LF = 640, 480, 9
+    cam = (0, 0, 0, 0, -60, -700)
+    objs = c1_scene()
+    ref = R.Ref(W, H)
+    ref.clear(0x000000, 0, 0, 0)
+    out = {}
+    for i, o in enumerate(objs):
+        m = ref.make_matrix(cam, (0, 0, 0, 0, 0, 0), LF)     # also sets the reference's camera
+        ref.render_object(o["verts"], o["polys"], None, o["polyverts"], S.M_SHADED, (0, 0, 0), (0, 0, 0))
+        out[f"obj{i}_verts"], out[f"obj{i}_polys"], out[f"obj{i}_polyverts"] = o["verts"], o["polys"], o["polyverts"]
+        out[f"obj{i}_m12"] = m
+    out["n_objs"] = np.array([len(objs)], np.int32)
+    out["meta"] = np.array([W, H, LF], np.int32)
+    out["colour"] = ref.cbuf().copy()
+    out["depth"] = ref.zbuf().copy()
+    return out
+
+
+def main():
+    if not os.path.isdir(REFDIR):
+        raise SystemExit("needs /root/reference (run in the build container)")
+    np.savez_compressed(os.path.join(HERE, "stage_kats.npz"), **stage_kats())
+    frames, crops = {}, {}
+    for name, spec in frame_cases():
+        sc = build_scene(spec)
+        c, z = render_ref(sc)
+        frames[name] = dict(spec=spec, clear=list(CLEAR), colour=S.frame_digest(c), depth=S.frame_digest(z),
+                            drawn_pixels=int((z != 2 ** 31 - 1).sum()))
+        if name.startswith("c2small-640") or name.startswith("c3mix"):
+            crops[name + "_c"] = c[200:232, 300:332].copy()
+            crops[name + "_z"] = z[200:232, 300:332].copy()
+        print(name, frames[name]["colour"], frames[name]["depth"], frames[name]["drawn_pixels"])
+    json.dump(frames, open(os.path.join(HERE, "frames.json"), "w"), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "crops.npz"), **crops)
+    c1 = c1_golden()
+    print("c1 drawn pixels", int((c1["depth"] != 2 ** 31 - 1).sum()))
+    np.savez_compressed(os.path.join(HERE, "c1_scene.npz"), **c1)
+
+
+if __name__ == "__main__":
+    main()
