@@ -112,6 +112,21 @@ int collect(lt_ctx *c)
     return LT_OK;
 }
 
+// sum of the device status slots; the stream must be idle
+int read_status(lt_ctx *c, Status *out)
+{
+    static_assert(sizeof(Status) == 8 * sizeof(unsigned long long), "Status is eight counters");
+    std::vector<Status> slots(STATUS_SLOTS);
+    HIPCHK(c, hipMemcpy(slots.data(), c->status, sizeof(Status) * STATUS_SLOTS, hipMemcpyDeviceToHost));
+    unsigned long long *o = (unsigned long long *)out;
+    for (int k = 0; k < 8; k++) o[k] = 0;
+    for (const Status &s : slots) {
+        const unsigned long long *v = (const unsigned long long *)&s;
+        for (int k = 0; k < 8; k++) o[k] += v[k];
+    }
+    return LT_OK;
+}
+
 int use_device(lt_ctx *c)
 {
     HIPCHK(c, hipSetDevice(c->device));
@@ -151,22 +166,30 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.W = c->W; sa.H = c->H; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.emax = emax;
     sa.hdr = (PrimHdr *)c->hdr.p; sa.edges = (int *)c->edges.p;
-    sa.tile_count = (unsigned *)c->tcount.p; sa.status = c->status;
+    sa.status = c->status;
     launch_setup(c->stream, dim, screen, sa);
     if ((rc = mark(c))) return rc;
 
-    launch_scan(c->stream, (const unsigned *)c->tcount.p, (unsigned *)c->toffset.p, (unsigned *)c->tcursor.p,
-                c->ntiles, capacity, c->status);
-    if ((rc = mark(c))) return rc;
-    launch_bin(c->stream, (const PrimHdr *)c->hdr.p, np, c->tiles_x, (const unsigned *)c->toffset.p,
-               (unsigned *)c->tcursor.p, (unsigned *)c->list.p, capacity, c->status);
+    // the scan mark is recorded inside launch_binning: count belongs to the "scan" stage
+    hipEvent_t scan_ev = nullptr;
+    if (c->profiling) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreate(&e));
+            c->ev_pool.push_back(e);
+        }
+        scan_ev = c->ev_pool[c->ev_used++];
+    }
+    launch_binning(c->stream, (const PrimHdr *)c->hdr.p, np, c->tiles_x, c->ntiles, (unsigned *)c->tcount.p,
+                   (unsigned *)c->toffset.p, (unsigned *)c->tcursor.p, (unsigned *)c->list.p, capacity, c->status,
+                   scan_ev);
     if ((rc = mark(c))) return rc;
 
     RasterArgs ra{};
     ra.hdr = (const PrimHdr *)c->hdr.p; ra.edges = (const int *)c->edges.p;
     ra.tile_offset = (const unsigned *)c->toffset.p; ra.tile_fill = (const unsigned *)c->tcursor.p;
     ra.tile_list = (const unsigned *)c->list.p; ra.list_capacity = capacity;
-    ra.emax = emax;
+    ra.np = np; ra.emax = emax;
     ra.W = c->W; ra.H = c->H; ra.tiles_x = c->tiles_x; ra.tiles_y = c->tiles_y;
     ra.cbuf = c->cbuf; ra.zbuf = c->zbuf;
     ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
@@ -224,8 +247,8 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     CREATECHK(hipSetDevice(device));
     CREATECHK(hipMalloc((void **)&c->cbuf, n * sizeof(int)));
     CREATECHK(hipMalloc((void **)&c->zbuf, n * sizeof(int)));
-    CREATECHK(hipMalloc((void **)&c->status, sizeof(Status)));
-    CREATECHK(hipMemset(c->status, 0, sizeof(Status)));
+    CREATECHK(hipMalloc((void **)&c->status, sizeof(Status) * STATUS_SLOTS));
+    CREATECHK(hipMemset(c->status, 0, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMalloc((void **)&c->tex_ptr_d, sizeof(int *) * LT_MAX_TEXTURES));
     CREATECHK(hipMalloc((void **)&c->tex_log_d, sizeof(int) * LT_MAX_TEXTURES));
     CREATECHK(hipMemset((void *)c->tex_ptr_d, 0, sizeof(int *) * LT_MAX_TEXTURES));
@@ -304,7 +327,7 @@ int lt_flush(lt_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if ((rc = collect(c))) return rc;
     Status s;
-    HIPCHK(c, hipMemcpy(&s, c->status, sizeof s, hipMemcpyDeviceToHost));
+    if ((rc = read_status(c, &s))) return rc;
     if (s.list_overflow > c->base.list_overflow) {
         c->base.list_overflow = s.list_overflow;
         return fail(c, LT_ERR_CAPACITY,
@@ -361,7 +384,7 @@ int lt_get_counters(lt_ctx *c, lt_counters *out)
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     Status s;
-    HIPCHK(c, hipMemcpy(&s, c->status, sizeof s, hipMemcpyDeviceToHost));
+    if ((rc = read_status(c, &s))) return rc;
     out->fragments = s.fragments;
     out->polys_in = c->polys_in;
     out->polys_drawn = s.polys_drawn;
@@ -378,7 +401,7 @@ int lt_reset_counters(lt_ctx *c)
     if (!c) return LT_ERR_ARG;
     int rc = use_device(c);
     if (rc) return rc;
-    HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(Status), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(Status) * STATUS_SLOTS, c->stream));
     c->base = Status{};
     c->polys_in = 0;
     return LT_OK;

@@ -20,12 +20,19 @@ constexpr int SETUP_THREADS = 128;
 //   meta  = n_edges | kind<<8 | tex<<16 ; n_edges == 0 marks "nothing to draw"
 struct PrimHdr { int yy, xx, colour, meta; };
 
-// Edge record (ints): {x1|y1<<16, x2|y2<<16, start[NA], inc[NA]} after the y clip of
-// GI_scan (GraphicsPoly.cpp:136).  start[0] = Z1<<16, inc[0] = ((Z2-Z1)<<16)/L; the
-// other values as in GraphicsPoly.cpp:171-176.  NA = 1 (flat), 4 (shaded), 6 (textured).
-__host__ __device__ constexpr int edge_ints(int na) { return 2 + 2 * na; }
+// Edge record after the y clip of GI_scan (GraphicsPoly.cpp:136), in 16-byte pieces:
+//   {x1|y1<<16, x2|y2<<16, Zstart, Zinc, start[1..NA-1], inc[1..NA-1], padding}
+// Zstart = Z1<<16, Zinc = ((Z2-Z1)<<16)/L; the other values as in GraphicsPoly.cpp:171-176.
+// NA = 1 (flat: 4 ints), 4 (shaded: 12 ints), 6 (textured: 16 ints).  The depth pass
+// reads only the first piece.  Edge k of polygon p lives at edges[(k*np + p)*ESZ]: a
+// wave of the setup kernel writes consecutive records, and no allocation is needed.
+__host__ __device__ constexpr int edge_ints(int na) { return na == 1 ? 4 : (na == 4 ? 12 : 16); }
 
-// Device status block, read back at lt_flush.
+// Device status block, read back at lt_flush.  There are STATUS_SLOTS copies and a
+// workgroup adds into slot blockIdx % STATUS_SLOTS: thousands of waves adding to one
+// word would queue behind each other (one chip-wide atomic per ~12 ns on one address);
+// the host sums the slots.
+constexpr int STATUS_SLOTS = 256;
 struct Status {
     unsigned long long fragments;
     unsigned long long polys_drawn;
@@ -50,7 +57,6 @@ struct SetupArgs {
     int emax;                // edge slots per polygon
     PrimHdr *hdr;
     int *edges;
-    unsigned *tile_count;
     Status *status;
 };
 
@@ -61,6 +67,7 @@ struct RasterArgs {
     const unsigned *tile_fill;     // entries actually written per tile
     const unsigned *tile_list;
     unsigned long long list_capacity;
+    int np;
     int emax;
     int W, H, tiles_x, tiles_y;
     int *cbuf, *zbuf;
@@ -72,10 +79,10 @@ struct RasterArgs {
 
 void launch_transform(hipStream_t s, const int *m12_dev, const int *from, int *to, int n);
 void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
-void launch_scan(hipStream_t s, const unsigned *count, unsigned *offset, unsigned *cursor, int ntiles,
-                 unsigned long long capacity, Status *status);
-void launch_bin(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, const unsigned *offset,
-                unsigned *cursor, unsigned *list, unsigned long long capacity, Status *status);
+// tile lists: count -> exclusive scan -> scatter (count must be zero before the call)
+void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
+                    unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
+                    Status *status, hipEvent_t after_scan);
 void launch_raster(hipStream_t s, int na, const RasterArgs &a);
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 

@@ -27,6 +27,39 @@ __device__ __forceinline__ int tdiv(int a, int b)
     return a / b;
 }
 
+// Exact truncating division through the double-precision unit, several times cheaper
+// than the 32-bit integer divide sequence.  For integers n and d >= 1,
+// trunc(n/d) = sign(n) * floor((|n| + 1/2) / d): the half never reaches the next
+// multiple of d, and it keeps the product at least 1/(2d) away from every integer, far
+// more than the rounding error of the multiply (|n| * 2^-51 / d for |n| < 2^50).
+// drcp(d) is 1/d to double precision (v_rcp_f64 + two Newton steps), shared by all
+// numerators that have the same divisor.
+__device__ __forceinline__ double drcp(int d)
+{
+    const double x = (double)d;
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ int tdivr(int n, double r)
+{
+    const double h = n < 0 ? -0.5 * r : 0.5 * r;
+    return (int)fma((double)n, r, h);
+}
+
+// floor(n / d) for 0 <= n < 2^30 and 1 <= d <= 2^15 with a quotient below 2^15 (the
+// point-index divisions of the edge walk): single-precision estimate, then one exact
+// correction step from the remainder.
+__device__ __forceinline__ int udiv_small(int n, int d)
+{
+    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
+    int r = n - q * d;
+    if (r < 0) { q--; r += d; }
+    if (r >= d) q++;
+    return q;
+}
+
 // CL_light (Colour.cpp:93-102): per channel (c*min(l,255))/255, evaluated
 // arithmetically instead of through the 256x256 table of Colour.cpp:44-56.  A
 // negative light is outside the table in the reference (Colour.h:135 clamps only from
@@ -160,10 +193,10 @@ __device__ __forceinline__ bool clip_line(const Tup<DIM> &v1, const Tup<DIM> &v2
 
 // T_perspective (TransBs.cpp:425-429): (int)(((long)x << log_focus) / z).  The 64-bit
 // quotient is only needed when x << log_focus leaves 32 bits.
-__device__ __forceinline__ int persp_div(int x, int lf, int z)
+__device__ __forceinline__ int persp_div(int x, int lf, int z, double rz)
 {
     int xs = wshl(x, lf);
-    if ((xs >> lf) == x) return xs / z;
+    if ((xs >> lf) == x) return tdivr(xs, rz);
     return (int)(((long long)x * ((long long)1 << lf)) / (long long)z);
 }
 
@@ -215,17 +248,75 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     }
     if (kind == KIND_TEX_LIN && (tex < 0 || tex >= 64)) { unsupported = true; go = false; }
 
+    // ---- read the polygon's tuples.  Polygons of up to PRE tuples (triangles, quads) are
+    // read up front -- all records at once, then all vertices at once -- so that a lane
+    // pays three dependent memory round trips (descriptor, records, vertices) instead of
+    // two per tuple; longer polygons read each tuple when the stream needs it.
+    constexpr int PRE = 5;
+    Tup<DIM> tin[PRE];
+#pragma unroll
+    for (int i = 0; i < PRE; i++) tin[i] = Tup<DIM>();
+    const bool pre = go && e + 1 <= PRE;
+    if (pre) {
+        if (SCREEN) {
+#pragma unroll
+            for (int i = 0; i < PRE; i++)
+                if (i <= e) {
+                    const int *src = a.polyverts + (size_t)(first + i) * DIM;
+#pragma unroll
+                    for (int j = 0; j < DIM; j++) tin[i].v[j] = src[j];
+                }
+        } else {
+            int2 ra[PRE], rb[PRE], rc[PRE];
+#pragma unroll
+            for (int i = 0; i < PRE; i++) {
+                ra[i] = make_int2(0, 0); rb[i] = ra[i]; rc[i] = ra[i];
+                if (i <= e) {
+                    const int2 *rec = (const int2 *)(a.polyverts + (size_t)(first + i) * 6);
+                    ra[i] = rec[0];
+                    if (DIM >= 6) rb[i] = rec[1];
+                    if (DIM == 8) rc[i] = rec[2];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PRE; i++)
+                if (i <= e) {
+                    if ((unsigned)ra[i].x >= (unsigned)a.nv) { bad = true; go = false; }
+                    else {
+                        // CI_construct_tuples, EngBase.cpp:58-137
+                        int4 p = load_vertex(a, ra[i].x);
+                        tin[i].v[0] = p.x; tin[i].v[1] = p.y; tin[i].v[2] = p.z;
+                        if (DIM >= 6) { tin[i].v[3] = wshl(ra[i].y, 16); tin[i].v[4] = wshl(rb[i].x, 16); tin[i].v[5] = wshl(rb[i].y, 16); }
+                        if (DIM == 8) {
+                            bool tx = kind == KIND_TEX_LIN;
+                            tin[i].v[DIM - 2] = tx ? wshl(rc[i].x, 16) : 0;
+                            tin[i].v[DIM - 1] = tx ? wshl(rc[i].y, 16) : 0;
+                        }
+                    }
+                }
+        }
+    }
+
     // ---- pass 1 (object mode): extent of the e+1 tuples, C_volume_clipping (Clipp3D.cpp:46-58)
     bool zclip = false;
     if (!SCREEN && go) {
         int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
-        for (int i = 0; i <= e; i++) {
-            int idx = a.polyverts[(size_t)(first + i) * 6];
-            if ((unsigned)idx >= (unsigned)a.nv) { bad = true; go = false; break; }
-            int4 p = load_vertex(a, idx);
-            mn[0] = min(mn[0], p.x); mx[0] = max(mx[0], p.x);
-            mn[1] = min(mn[1], p.y); mx[1] = max(mx[1], p.y);
-            mn[2] = min(mn[2], p.z); mx[2] = max(mx[2], p.z);
+        if (pre) {
+#pragma unroll
+            for (int i = 0; i < PRE; i++)
+                if (i <= e) {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) { mn[j] = min(mn[j], tin[i].v[j]); mx[j] = max(mx[j], tin[i].v[j]); }
+                }
+        } else {
+            for (int i = 0; i <= e; i++) {
+                int idx = a.polyverts[(size_t)(first + i) * 6];
+                if ((unsigned)idx >= (unsigned)a.nv) { bad = true; go = false; break; }
+                int4 p = load_vertex(a, idx);
+                mn[0] = min(mn[0], p.x); mx[0] = max(mx[0], p.x);
+                mn[1] = min(mn[1], p.y); mx[1] = max(mx[1], p.y);
+                mn[2] = min(mn[2], p.z); mx[2] = max(mx[2], p.z);
+            }
         }
         if (go) {
             if ((mx[2] < mn[0]) || (mx[2] < mn[1]) || (mx[2] < -mx[0]) || (mx[2] < -mx[1]) || (mx[2] <= 10))
@@ -236,7 +327,6 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     }
 
     // ---- the stream
-    int *erec = a.edges + (size_t)poly * a.emax * ESZ;
     int ne = 0;                       // edge records written
     int miny = INT_MAX, maxy = INT_MIN, minx = INT_MAX, maxx = INT_MIN;
     Tup<DIM> zprev, zfirst;           // Z stage: previous input tuple / first output tuple
@@ -257,11 +347,14 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 
         if (it <= e) {
             Tup<DIM> t;
-            if (SCREEN) {
+            if (pre) {
+                t = tin[0];
+#pragma unroll
+                for (int i = 1; i < PRE; i++) t = sel(it == i, tin[i], t);
+            } else if (SCREEN) {
                 const int *src = a.polyverts + (size_t)(first + it) * DIM;
 #pragma unroll
                 for (int j = 0; j < DIM; j++) t.v[j] = src[j];
-                zo0 = t; zclosing0 = (it == e); cz = 1;
             } else {
                 // CI_construct_tuples, EngBase.cpp:58-137
                 const int *rec = a.polyverts + (size_t)(first + it) * 6;
@@ -273,6 +366,10 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                     t.v[DIM - 2] = tx ? wshl(rec[4], 16) : 0;
                     t.v[DIM - 1] = tx ? wshl(rec[5], 16) : 0;
                 }
+            }
+            if (SCREEN) {
+                zo0 = t; zclosing0 = (it == e); cz = 1;
+            } else {
                 if (!zclip) {
                     zo0 = t; zclosing0 = (it == e); cz = 1;
                 } else if (it > 0) {
@@ -302,10 +399,11 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                     if (zn + 1 > 16) bad = true;
                 }
                 // T_perspective, TransBs.cpp:425-432
-                int z = p.v[2];
-                p.v[0] = wadd(persp_div(p.v[0], a.log_focus, z), xc);
-                p.v[1] = wadd(persp_div(p.v[1], a.log_focus, z), yc);
-                p.v[2] = (int)(-0x7ffff / z);
+                const int z = p.v[2];               // >= 10 after the volume test and the near clip
+                const double rz = drcp(z);
+                p.v[0] = wadd(persp_div(p.v[0], a.log_focus, z, rz), xc);
+                p.v[1] = wadd(persp_div(p.v[1], a.log_focus, z, rz), yc);
+                p.v[2] = tdivr(-0x7ffff, rz);
                 int seq = closing ? zn : zn - 1;
                 if (seq < 3) {
                     // static indices keep px/py in registers
@@ -351,16 +449,25 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                         dy = dy < 0 ? -dy : dy;
                         int L = dx > dy ? dx : dy;
                         if (ne < a.emax) {
-                            int *r = erec + ne * ESZ;
-                            r[0] = x1 | (y1 << 16);
-                            r[1] = x2 | (y2 << 16);
-                            r[2] = wshl(v1.v[2], 16);
-                            r[2 + NA] = L > 0 ? tdiv(wshl(wsub(v2.v[2], v1.v[2]), 16), L) : 0;
+                            // record = {x1|y1<<16, x2|y2<<16, Z start, Z inc, other starts.., other incs..},
+                            // 16-byte pieces; edge k of every polygon lies in plane k of the pool
+                            int rec[ESZ];
+#pragma unroll
+                            for (int q = 0; q < ESZ; q++) rec[q] = 0;
+                            rec[0] = x1 | (y1 << 16);
+                            rec[1] = x2 | (y2 << 16);
+                            const double rL = drcp(L > 0 ? L : 1);
+                            rec[2] = wshl(v1.v[2], 16);
+                            rec[3] = L > 0 ? tdivr(wshl(wsub(v2.v[2], v1.v[2]), 16), rL) : 0;
 #pragma unroll
                             for (int q = 1; q < NA; q++) {
-                                r[2 + q] = v1.v[2 + q];
-                                r[2 + NA + q] = L > 0 ? tdiv(wsub(v2.v[2 + q], v1.v[2 + q]), L) : 0;
+                                rec[3 + q] = v1.v[2 + q];
+                                rec[3 + (NA - 1) + q] = L > 0 ? tdivr(wsub(v2.v[2 + q], v1.v[2 + q]), rL) : 0;
                             }
+                            int4 *r = (int4 *)(a.edges + ((size_t)ne * a.np + poly) * ESZ);
+#pragma unroll
+                            for (int q = 0; q < ESZ / 4; q++)
+                                r[q] = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
                         }
                         ne++;
                     }
@@ -405,24 +512,128 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
         hdr.xx = minx | (maxx << 16);
         hdr.colour = col;
         hdr.meta = ne | (kind << 8) | ((tex < 0 ? 0 : tex) << 16);
-        // one reference per tile of the bounding box (rows miny .. maxy-1)
-        int tx0 = minx / TW, tx1 = maxx / TW, ty0 = miny / TH, ty1 = (maxy - 1) / TH;
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tile_count[ty * a.tiles_x + tx], 1u);
     }
     ((int4 *)a.hdr)[poly] = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
 
-    // counters: one atomic per wave
+    // counters: one atomic per wave, spread over the status slots
+    Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
     unsigned long long m;
     m = __ballot(reached_fill);
-    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&a.status->polys_drawn, (unsigned long long)__popcll(m));
+    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(m));
     m = __ballot(bad);
-    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&a.status->overflow_polys, (unsigned long long)__popcll(m));
+    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->overflow_polys, (unsigned long long)__popcll(m));
     m = __ballot(unsupported);
-    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&a.status->unsupported_polys, (unsigned long long)__popcll(m));
+    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->unsupported_polys, (unsigned long long)__popcll(m));
 }
 
 // ------------------------------------------------------------------ binning
+
+// Tile lists are built by a counting sort over (polygon, tile) references: count per
+// tile, exclusive scan, scatter.  A workgroup takes a contiguous chunk of polygons and
+// keeps its own per-tile histogram in LDS, so the chip-wide atomics shrink from one per
+// reference to one per (chunk, touched tile).  The order of a list's entries does not
+// matter: the fill resolves by (depth, draw index).
+constexpr int BIN_THREADS = 512;
+constexpr int BIN_PER_THREAD = 8;
+constexpr int BIN_CHUNK = BIN_THREADS * BIN_PER_THREAD;
+constexpr int BIN_MAX_TILES = 8192;        // LDS histogram limit; larger screens take the direct kernels
+
+__device__ __forceinline__ bool prim_tiles(const int4 h, int &tx0, int &tx1, int &ty0, int &ty1)
+{
+    if ((h.w & 0xff) == 0) return false;
+    int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff, minx = h.y & 0xffff, maxx = (h.y >> 16) & 0xffff;
+    tx0 = minx / TW; tx1 = maxx / TW; ty0 = miny / TH; ty1 = (maxy - 1) / TH;
+    return true;
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+                                                            int ntiles, unsigned *__restrict__ count)
+{
+    __shared__ unsigned hist[BIN_MAX_TILES];
+    for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * BIN_CHUNK;
+#pragma unroll
+    for (int k = 0; k < BIN_PER_THREAD; k++) {
+        int poly = base + k * BIN_THREADS + threadIdx.x;
+        if (poly < np) {
+            int tx0, tx1, ty0, ty1;
+            if (prim_tiles(((const int4 *)hdr)[poly], tx0, tx1, ty0, ty1))
+                for (int ty = ty0; ty <= ty1; ty++)
+                    for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * tiles_x + tx], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS)
+        if (hist[i]) atomicAdd(&count[i], hist[i]);
+}
+
+__global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+                                                              int ntiles, const unsigned *__restrict__ offset,
+                                                              unsigned *__restrict__ cursor, unsigned *__restrict__ list,
+                                                              unsigned long long capacity)
+{
+    __shared__ unsigned hist[BIN_MAX_TILES];      // count, then the chunk's base slot inside the tile's list
+    for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * BIN_CHUNK;
+    int4 hs[BIN_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < BIN_PER_THREAD; k++) {
+        int poly = base + k * BIN_THREADS + threadIdx.x;
+        hs[k] = poly < np ? ((const int4 *)hdr)[poly] : make_int4(0, 0, 0, 0);
+        int tx0, tx1, ty0, ty1;
+        if (prim_tiles(hs[k], tx0, tx1, ty0, ty1))
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * tiles_x + tx], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) {
+        unsigned h = hist[i];
+        if (h) hist[i] = offset[i] + atomicAdd(&cursor[i], h);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < BIN_PER_THREAD; k++) {
+        int poly = base + k * BIN_THREADS + threadIdx.x;
+        int tx0, tx1, ty0, ty1;
+        if (prim_tiles(hs[k], tx0, tx1, ty0, ty1))
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) {
+                    unsigned slot = atomicAdd(&hist[ty * tiles_x + tx], 1u);
+                    if ((unsigned long long)slot < capacity) list[slot] = (unsigned)poly;
+                }
+    }
+}
+
+// direct versions for screens with more tiles than the LDS histogram holds
+__global__ void __launch_bounds__(256) count_direct_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+                                                           unsigned *__restrict__ count)
+{
+    int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    if (poly >= np) return;
+    int tx0, tx1, ty0, ty1;
+    if (prim_tiles(((const int4 *)hdr)[poly], tx0, tx1, ty0, ty1))
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&count[ty * tiles_x + tx], 1u);
+}
+
+__global__ void __launch_bounds__(256) scatter_direct_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+                                                             const unsigned *__restrict__ offset,
+                                                             unsigned *__restrict__ cursor, unsigned *__restrict__ list,
+                                                             unsigned long long capacity)
+{
+    int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    if (poly >= np) return;
+    int tx0, tx1, ty0, ty1;
+    if (prim_tiles(((const int4 *)hdr)[poly], tx0, tx1, ty0, ty1))
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                int tile = ty * tiles_x + tx;
+                unsigned slot = offset[tile] + atomicAdd(&cursor[tile], 1u);
+                if ((unsigned long long)slot < capacity) list[slot] = (unsigned)poly;
+            }
+}
 
 // Exclusive prefix sum of the per-tile reference counts (one workgroup; the tile count
 // is at most a few hundred thousand).  Also zeroes the scatter cursors.
@@ -462,26 +673,6 @@ __global__ void __launch_bounds__(1024) scan_kernel(const unsigned *__restrict__
     }
 }
 
-// One polygon per lane: append its index to the list of every tile of its bounding
-// box.  The order inside a list does not matter (the fill resolves by (depth, index)).
-__global__ void __launch_bounds__(256) bin_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
-                                                  const unsigned *__restrict__ offset, unsigned *__restrict__ cursor,
-                                                  unsigned *__restrict__ list, unsigned long long capacity)
-{
-    int poly = blockIdx.x * blockDim.x + threadIdx.x;
-    if (poly >= np) return;
-    int4 h = ((const int4 *)hdr)[poly];
-    if ((h.w & 0xff) == 0) return;
-    int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff, minx = h.y & 0xffff, maxx = (h.y >> 16) & 0xffff;
-    int tx0 = minx / TW, tx1 = maxx / TW, ty0 = miny / TH, ty1 = (maxy - 1) / TH;
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
-            int tile = ty * tiles_x + tx;
-            unsigned slot = offset[tile] + atomicAdd(&cursor[tile], 1u);
-            if ((unsigned long long)slot < capacity) list[slot] = (unsigned)poly;
-        }
-}
-
 // ------------------------------------------------------------------ fill
 
 // The two ends of one polygon row as GI_scan leaves them in G_x_start / G_x_end and
@@ -498,44 +689,55 @@ __global__ void __launch_bounds__(256) bin_kernel(const PrimHdr *__restrict__ hd
 //    in wrapping arithmetic);
 //  - the compares of GraphicsPoly.cpp:180,187 are strict, so on equal x the earlier
 //    edge keeps the row end.
+// edge_row() gives, for one edge and one row, the point index and x of the row's
+// leftmost and rightmost point on that edge; it returns false if the edge misses the row.
+__device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &xa, int &ib, int &xb)
+{
+    int x1 = xy1 & 0xffff, y1 = (xy1 >> 16) & 0xffff, x2 = xy2 & 0xffff, y2 = (xy2 >> 16) & 0xffff;
+    int dx = x2 - x1, dy = y2 - y1;
+    int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    int j = dy < 0 ? y1 - y : y - y1;
+    if ((unsigned)j > (unsigned)ady) return false;
+    if (adx > ady) {
+        int L = adx, s = ady, ilo, ihi;
+        if (s == 0) { ilo = 0; ihi = L; }
+        else {
+            ilo = j == 0 ? 0 : udiv_small(2 * L * j - L + 2 * s - 1, 2 * s);
+            ihi = j == s ? L : udiv_small(2 * L * (j + 1) - L + 2 * s - 1, 2 * s) - 1;
+        }
+        if (dx >= 0) { ia = ilo; ib = ihi; xa = x1 + ilo; xb = x1 + ihi; }
+        else         { ia = ihi; ib = ilo; xa = x1 - ihi; xb = x1 - ilo; }
+    } else {
+        int L = ady, s = adx;
+        int h = L == 0 ? 0 : udiv_small(2 * s * j + L, 2 * L);
+        ia = ib = j;
+        xa = xb = dx < 0 ? x1 - h : x1 + h;
+    }
+    return true;
+}
+
+// Row ends with all NA interpolated values (used by the colour pass).
 template <int NA>
-__device__ __forceinline__ bool row_ends(const int *__restrict__ er, int ne, int y, int &beg, int &end,
-                                         int (&S)[NA], int (&E)[NA])
+__device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, int poly, int ne, int y, int &beg,
+                                         int &end, int (&S)[NA], int (&E)[NA])
 {
     constexpr int ESZ = edge_ints(NA);
     int bx = INT_MAX, ex = INT_MIN, be = 0, bi = 0, ee = 0, ei = 0;
     for (int e = 0; e < ne; e++) {
-        const int2 xy = *(const int2 *)(er + e * ESZ);
-        int x1 = xy.x & 0xffff, y1 = (xy.x >> 16) & 0xffff, x2 = xy.y & 0xffff, y2 = (xy.y >> 16) & 0xffff;
-        int dx = x2 - x1, dy = y2 - y1;
-        int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-        int j = dy < 0 ? y1 - y : y - y1;
-        if ((unsigned)j > (unsigned)ady) continue;
-        int ia, ib, xa, xb;                 // point index and x of the row's min-x / max-x point
-        if (adx > ady) {
-            int L = adx, s = ady, ilo, ihi;
-            if (s == 0) { ilo = 0; ihi = L; }
-            else {
-                ilo = j == 0 ? 0 : (2 * L * j - L + 2 * s - 1) / (2 * s);
-                ihi = j == s ? L : (2 * L * (j + 1) - L + 2 * s - 1) / (2 * s) - 1;
-            }
-            if (dx >= 0) { ia = ilo; ib = ihi; xa = x1 + ilo; xb = x1 + ihi; }
-            else         { ia = ihi; ib = ilo; xa = x1 - ihi; xb = x1 - ilo; }
-        } else {
-            int L = ady, s = adx;
-            int h = L == 0 ? 0 : (2 * s * j + L) / (2 * L);
-            ia = ib = j;
-            xa = xb = dx < 0 ? x1 - h : x1 + h;
-        }
+        const int2 xy = *(const int2 *)(edges + ((size_t)e * np + poly) * ESZ);
+        int ia, xa, ib, xb;
+        if (!edge_row(xy.x, xy.y, y, ia, xa, ib, xb)) continue;
         if (xa < bx) { bx = xa; be = e; bi = ia; }
         if (ex < xb) { ex = xb; ee = e; ei = ib; }
     }
     if (bx == INT_MAX) return false;
-    const int *rb = er + be * ESZ + 2, *re = er + ee * ESZ + 2;
+    const int *rb = edges + ((size_t)be * np + poly) * ESZ, *re = edges + ((size_t)ee * np + poly) * ESZ;
+    S[0] = wadd(rb[2], wmul(bi, rb[3]));
+    E[0] = wadd(re[2], wmul(ei, re[3]));
 #pragma unroll
-    for (int q = 0; q < NA; q++) {
-        S[q] = wadd(rb[q], wmul(bi, rb[NA + q]));
-        E[q] = wadd(re[q], wmul(ei, re[NA + q]));
+    for (int q = 1; q < NA; q++) {
+        S[q] = wadd(rb[3 + q], wmul(bi, rb[3 + (NA - 1) + q]));
+        E[q] = wadd(re[3 + q], wmul(ei, re[3 + (NA - 1) + q]));
     }
     beg = bx;
     end = ex;
@@ -547,28 +749,74 @@ __device__ __forceinline__ unsigned long long depth_key(int z, unsigned id)
     return ((unsigned long long)((unsigned)z ^ 0x80000000u) << 32) | id;
 }
 
-// One workgroup per screen tile.  LDS holds the tile's packed (depth, draw index) keys
-// and its colours.  The tile's polygon list is taken 256 polygons at a time; their rows
-// inside the tile are numbered through a prefix sum and dealt one row per lane, 256 rows
-// per round.  Round = phase A: every lane walks its span and lowers the keys with
-// ds_min_u64; barrier; phase B: every lane walks its span again and, where the key is
-// still its own, computes and stores the colour.  A later round or chunk that wins a
-// pixel overwrites the colour in its own phase B, which the barrier orders after this
-// one.  The frame is read from HBM once per tile (or not at all right after a clear)
-// and written once.
+// Depth span of one row from up to three edges held in registers (the depth pass of
+// triangles), or from memory for polygons with more edges.  Returns false if no edge
+// touches the row.  zs = depth accumulator at beg (16.16), zi = per-pixel increment
+// (GraphicsPoly.cpp:352-353; the flat fill skips the divide when end == beg, which
+// leaves the single pixel's depth unchanged: GraphicsPoly.cpp:273).
+struct Edge4 { int xy1, xy2, z0, zi; };
+
+__device__ __forceinline__ bool depth_row3(const Edge4 (&ed)[3], int ne, int y, int &beg, int &end, int &zs, int &zi)
+{
+    int bx = INT_MAX, ex = INT_MIN, sz = 0, ez = 0;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        int ia, xa, ib, xb;
+        if (e < ne && edge_row(ed[e].xy1, ed[e].xy2, y, ia, xa, ib, xb)) {
+            if (xa < bx) { bx = xa; sz = wadd(ed[e].z0, wmul(ia, ed[e].zi)); }
+            if (ex < xb) { ex = xb; ez = wadd(ed[e].z0, wmul(ib, ed[e].zi)); }
+        }
+    }
+    if (bx == INT_MAX) return false;
+    int span = ex - bx;
+    if (span == 0) span = 1;
+    beg = bx; end = ex; zs = sz;
+    zi = tdivr(wsub(ez, sz), drcp(span));
+    return true;
+}
+
+__device__ __forceinline__ bool depth_row_mem(const int *__restrict__ edges, int esz, int np, int poly, int ne, int y,
+                                              int &beg, int &end, int &zs, int &zi)
+{
+    int bx = INT_MAX, ex = INT_MIN, sz = 0, ez = 0;
+    for (int e = 0; e < ne; e++) {
+        const int4 r = *(const int4 *)(edges + ((size_t)e * np + poly) * esz);
+        int ia, xa, ib, xb;
+        if (!edge_row(r.x, r.y, y, ia, xa, ib, xb)) continue;
+        if (xa < bx) { bx = xa; sz = wadd(r.z, wmul(ia, r.w)); }
+        if (ex < xb) { ex = xb; ez = wadd(r.z, wmul(ib, r.w)); }
+    }
+    if (bx == INT_MAX) return false;
+    int span = ex - bx;
+    if (span == 0) span = 1;
+    beg = bx; end = ex; zs = sz;
+    zi = tdivr(wsub(ez, sz), drcp(span));
+    return true;
+}
+
+// One workgroup per screen tile; LDS holds the tile's packed (depth, draw index) keys.
+//
+// Depth pass.  Lanes take the tile's polygons one each.  A polygon that is small inside
+// this tile is walked by its lane: row by row, pixel by pixel, lowering keys with
+// ds_min_u64.  A polygon that covers many pixels of the tile is left to the whole wave:
+// its rows are evaluated one per lane, then each row's span is swept 64 pixels per step,
+// one pixel per lane.  No lane waits for another workgroup-wide: the minimum is
+// commutative, so there are no barriers between polygons.
+//
+// Colour pass.  After a barrier every pixel of the tile knows its winner.  Each lane
+// takes pixels, looks up the winner's row (ends, start values, increments) and computes
+// that one colour: CL_light of the base colour or texel (GraphicsPoly.cpp:372,486).
+// Pixels that no polygon of this batch won keep what the frame held (or the clear
+// colour).  The frame is read (depth only) at most once per tile and written once.
+constexpr int BIG_AREA = 192;       // bounding box pixels inside the tile from which a polygon goes to the wave path
+
 template <int NA>
 __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
 {
     constexpr int ESZ = edge_ints(NA);
-    constexpr int KP = TW + 1;       // key row pitch in 8-byte words: lanes on consecutive rows hit different banks
-    __shared__ unsigned long long keys[TH * KP];
-    __shared__ int cols[TH * TW];
-    __shared__ int c_poly[RASTER_THREADS];
-    __shared__ int c_row0[RASTER_THREADS];
-    __shared__ int c_off[RASTER_THREADS + 1];
-    __shared__ int wsum[RASTER_THREADS / 64];
+    __shared__ unsigned long long keys[TH * TW];
 
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
     const int tile = blockIdx.x;
     const int tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
     const unsigned lbeg = a.tile_offset[tile];
@@ -577,142 +825,148 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         lcnt = a.list_capacity > lbeg ? (unsigned)(a.list_capacity - lbeg) : 0u;
     if (lcnt == 0 && !a.clear_pending) return;       // untouched tile of a frame that is already in HBM
 
-    // ---- tile in
+    // ---- tile in: depth only
     for (int p = t; p < TW * TH; p += RASTER_THREADS) {
         int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
-        int z = INT_MAX, c = a.clear_colour;
-        if (!a.clear_pending && gx < a.W && gy < a.H) {
-            z = a.zbuf[(size_t)gy * a.W + gx];
-            c = a.cbuf[(size_t)gy * a.W + gx];
-        }
-        keys[ly * KP + lx] = depth_key(z, 0u);
-        cols[ly * TW + lx] = c;
+        int z = INT_MAX;
+        if (!a.clear_pending && gx < a.W && gy < a.H) z = a.zbuf[(size_t)gy * a.W + gx];
+        keys[p] = depth_key(z, 0u);
     }
     __syncthreads();
 
-    unsigned long long frags = 0, qrows = 0;
+    unsigned long long frags = 0;
 
-    for (unsigned cbase = 0; cbase < lcnt; cbase += RASTER_THREADS) {
-        // ---- chunk: one polygon per lane, rows inside the tile, prefix sum
-        int poly = -1, r0 = 0, cnt = 0;
-        if (cbase + t < lcnt) {
-            poly = (int)a.tile_list[lbeg + cbase + t];
-            int yy = a.hdr[poly].yy;
-            int miny = yy & 0xffff, maxy = (yy >> 16) & 0xffff;
-            r0 = max(miny, ty0);
-            int r1 = min(maxy, ty0 + TH);
-            cnt = max(r1 - r0, 0);
-        }
-        int s = cnt;
+    // ---- depth pass
+    const unsigned rounds = (lcnt + RASTER_THREADS - 1) / RASTER_THREADS;
+    for (unsigned rd = 0; rd < rounds; rd++) {
+        const unsigned li = rd * RASTER_THREADS + t;
+        int poly = -1, ne = 0, r0 = 0, r1 = 0, cx0 = 0, cx1 = -1;
+        Edge4 ed[3];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int o = __shfl_up(s, d);
-            if (lane >= d) s += o;
+        for (int e = 0; e < 3; e++) { ed[e].xy1 = 0; ed[e].xy2 = 0; ed[e].z0 = 0; ed[e].zi = 0; }
+        if (li < lcnt) {
+            poly = (int)a.tile_list[lbeg + li];
+            const int4 h = ((const int4 *)a.hdr)[poly];
+            ne = h.w & 0xff;
+            r0 = max(h.x & 0xffff, ty0);
+            r1 = min((h.x >> 16) & 0xffff, ty0 + TH);
+            cx0 = max(h.y & 0xffff, tx0);
+            cx1 = min((h.y >> 16) & 0xffff, tx0 + TW - 1);
+#pragma unroll
+            for (int e = 0; e < 3; e++)
+                if (e < ne) {
+                    const int4 r = *(const int4 *)(a.edges + ((size_t)e * a.np + poly) * ESZ);
+                    ed[e].xy1 = r.x; ed[e].xy2 = r.y; ed[e].z0 = r.z; ed[e].zi = r.w;
+                }
         }
-        if (lane == 63) wsum[wv] = s;
-        __syncthreads();
-        int pre = 0;
-        for (int k = 0; k < wv; k++) pre += wsum[k];
-        c_poly[t] = poly;
-        c_row0[t] = r0;
-        c_off[t] = pre + s - cnt;
-        if (t == RASTER_THREADS - 1) c_off[RASTER_THREADS] = pre + s;
-        __syncthreads();
-        const int total = c_off[RASTER_THREADS];
+        const bool live = poly >= 0 && r0 < r1 && cx0 <= cx1;
+        const bool big = live && (r1 - r0) * (cx1 - cx0 + 1) >= BIG_AREA;
 
-        for (int rbase = 0; rbase < total; rbase += RASTER_THREADS) {
-            const int r = rbase + t;
-            bool act = r < total;
-            int y = 0, xa = 0, xb = -1, beg = 0, kind = 0, pcol = 0, ptex = 0;
-            unsigned id = 0;
-            int S[NA], I[NA];
-#pragma unroll
-            for (int q = 0; q < NA; q++) { S[q] = 0; I[q] = 0; }
-            if (act) {
-                // which polygon owns row r: last p with c_off[p] <= r
-                int lo = 0, hi = RASTER_THREADS - 1;
-                while (lo < hi) {
-                    int mid = (lo + hi + 1) >> 1;
-                    if (c_off[mid] <= r) lo = mid; else hi = mid - 1;
-                }
-                const int pp = c_poly[lo];
-                y = c_row0[lo] + (r - c_off[lo]);
-                const int4 h = ((const int4 *)a.hdr)[pp];
-                const int ne = h.w & 0xff;
-                kind = (h.w >> 8) & 0xff;
-                ptex = (h.w >> 16) & 0xff;
-                pcol = h.z;
-                id = (unsigned)pp + 1u;
-                int E[NA], end = 0;
-                act = row_ends<NA>(a.edges + (size_t)pp * a.emax * ESZ, ne, y, beg, end, S, E);
-                if (act) {
-                    // span set-up, GraphicsPoly.cpp:335-353 (flat: :269-274)
-                    int span = end - beg;
-                    if (span == 0) span = 1;
-#pragma unroll
-                    for (int q = 0; q < NA; q++) I[q] = tdiv(wsub(E[q], S[q]), span);
-                    if (NA == 6 && kind == KIND_TEX_LIN && ((I[1] | I[2] | I[3]) != 0)) qrows++;
-                    xa = max(beg, tx0);
-                    xb = min(end, tx0 + TW - 1);
-                    if (xa > xb) act = false;
-                    else frags += (unsigned long long)(xb - xa + 1);
-                }
-            }
-            // ---- phase A: depth
-            if (act) {
-                unsigned long long *krow = keys + (y - ty0) * KP - tx0;
-                int z = wadd(S[0], wmul(xa - beg, I[0]));
+        // small polygons: one lane each
+        if (live && !big) {
+            const unsigned id = (unsigned)poly + 1u;
+            for (int y = r0; y < r1; y++) {
+                int beg, end, zs, zi;
+                bool ok = ne <= 3 ? depth_row3(ed, ne, y, beg, end, zs, zi)
+                                  : depth_row_mem(a.edges, ESZ, a.np, poly, ne, y, beg, end, zs, zi);
+                if (!ok) continue;
+                int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
+                if (xa > xb) continue;
+                frags += (unsigned long long)(xb - xa + 1);
+                unsigned long long *krow = keys + (y - ty0) * TW - tx0;
+                int z = wadd(zs, wmul(xa - beg, zi));
                 for (int x = xa; x <= xb; x++) {
                     atomicMin(&krow[x], depth_key(z >> 16, id));
-                    z = wadd(z, I[0]);
+                    z = wadd(z, zi);
                 }
             }
-            __syncthreads();
-            // ---- phase B: colour of the fragments that hold their pixel
-            if (act) {
-                const unsigned long long *krow = keys + (y - ty0) * KP - tx0;
-                int *crow = cols + (y - ty0) * TW - tx0;
-                int z = wadd(S[0], wmul(xa - beg, I[0]));
-                for (int x = xa; x <= xb; x++) {
-                    if (krow[x] == depth_key(z >> 16, id)) {
-                        int c;
-                        if (NA == 1 || kind == KIND_FLAT) c = pcol;
-                        else {
-                            const int k = x - beg;
-                            int lr = wadd(S[1 % NA], wmul(k, I[1 % NA])) >> 16;
-                            int lg = wadd(S[2 % NA], wmul(k, I[2 % NA])) >> 16;
-                            int lb = wadd(S[3 % NA], wmul(k, I[3 % NA])) >> 16;
-                            int base = pcol;
-                            if (NA == 6 && kind == KIND_TEX_LIN) {
-                                // GraphicsPoly.cpp:465,486: wrap, then fetch the texel
-                                const int lg2 = a.tex_log[ptex];
-                                const int mask = wsub(wshl(1, lg2 + 16), 1);
-                                int tu = wadd(S[4 % NA], wmul(k, I[4 % NA])) & mask;
-                                int tv = wadd(S[5 % NA], wmul(k, I[5 % NA])) & mask;
-                                base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
-                            }
-                            c = cl_light(base, lr, lg, lb);
-                        }
-                        crow[x] = c;
-                    }
-                    z = wadd(z, I[0]);
-                }
-            }
-            // the next round's phase A may run beside this phase B: it only lowers keys,
-            // and a lane that loses its pixel here skips the store
         }
-        __syncthreads();        // the chunk tables are rewritten next
+
+        // large polygons: the wave takes them one after another
+        unsigned long long bigmask = __ballot(big);
+        while (bigmask) {
+            const int src = __ffsll((long long)bigmask) - 1;
+            bigmask &= bigmask - 1;
+            const int bpoly = __shfl(poly, src), bne = __shfl(ne, src);
+            const int br0 = __shfl(r0, src), br1 = __shfl(r1, src);
+            Edge4 be[3];
+#pragma unroll
+            for (int e = 0; e < 3; e++) {
+                be[e].xy1 = __shfl(ed[e].xy1, src); be[e].xy2 = __shfl(ed[e].xy2, src);
+                be[e].z0 = __shfl(ed[e].z0, src);   be[e].zi = __shfl(ed[e].zi, src);
+            }
+            const unsigned id = (unsigned)bpoly + 1u;
+            // rows of the tile are at most TH <= 64: lane l evaluates row br0 + l
+            int beg = 0, end = -1, zs = 0, zi = 0;
+            {
+                const int y = br0 + lane;
+                bool ok = false;
+                if (y < br1)
+                    ok = bne <= 3 ? depth_row3(be, bne, y, beg, end, zs, zi)
+                                  : depth_row_mem(a.edges, ESZ, a.np, bpoly, bne, y, beg, end, zs, zi);
+                if (!ok) { beg = 0; end = -1; }
+            }
+            const int nrows = br1 - br0;
+            const int x = tx0 + lane;                       // TW == 64: one pixel column per lane
+            for (int rr = 0; rr < nrows; rr++) {
+                const int rbeg = __shfl(beg, rr), rend = __shfl(end, rr);
+                const int rzs = __shfl(zs, rr), rzi = __shfl(zi, rr);
+                const bool in = x >= rbeg && x <= rend;
+                if (in) atomicMin(&keys[(br0 + rr - ty0) * TW + lane], depth_key(wadd(rzs, wmul(x - rbeg, rzi)) >> 16, id));
+                if (lane == 0) {
+                    int xa = max(rbeg, tx0), xb = min(rend, tx0 + TW - 1);
+                    if (xa <= xb) frags += (unsigned long long)(xb - xa + 1);
+                }
+            }
+        }
     }
     __syncthreads();
 
-    // ---- tile out
+    // ---- colour pass + tile out
+    unsigned long long qrows = 0;
     for (int p = t; p < TW * TH; p += RASTER_THREADS) {
-        int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
-        if (gx < a.W && gy < a.H) {
-            unsigned long long k = keys[ly * KP + lx];
-            a.zbuf[(size_t)gy * a.W + gx] = (int)((unsigned)(k >> 32) ^ 0x80000000u);
-            a.cbuf[(size_t)gy * a.W + gx] = cols[ly * TW + lx];
+        const int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
+        if (gx >= a.W || gy >= a.H) continue;
+        const unsigned long long k = keys[p];
+        const unsigned id = (unsigned)k;
+        const size_t g = (size_t)gy * a.W + gx;
+        if (id == 0u) {
+            if (a.clear_pending) { a.zbuf[g] = INT_MAX; a.cbuf[g] = a.clear_colour; }
+            continue;
         }
+        const int poly = (int)(id - 1u);
+        const int4 h = ((const int4 *)a.hdr)[poly];
+        const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff, ptex = (h.w >> 16) & 0xff;
+        int c = h.z;
+        if (NA > 1 && kind != KIND_FLAT) {
+            int S[NA], E[NA], beg = 0, end = 0;
+            row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E);
+            int span = end - beg;
+            if (span == 0) span = 1;
+            const int kx = gx - beg;
+            const double rs = drcp(span);
+            int I1 = tdivr(wsub(E[1 % NA], S[1 % NA]), rs);
+            int I2 = tdivr(wsub(E[2 % NA], S[2 % NA]), rs);
+            int I3 = tdivr(wsub(E[3 % NA], S[3 % NA]), rs);
+            int lr = wadd(S[1 % NA], wmul(kx, I1)) >> 16;
+            int lg = wadd(S[2 % NA], wmul(kx, I2)) >> 16;
+            int lb = wadd(S[3 % NA], wmul(kx, I3)) >> 16;
+            int base = h.z;
+            if (NA == 6 && kind == KIND_TEX_LIN) {
+                // GraphicsPoly.cpp:443-446,465,486: wrap, then fetch the texel
+                if ((I1 | I2 | I3) != 0) qrows++;
+                const int lg2 = a.tex_log[ptex];
+                const int mask = wsub(wshl(1, lg2 + 16), 1);
+                int I4 = tdivr(wsub(E[4 % NA], S[4 % NA]), rs);
+                int I5 = tdivr(wsub(E[5 % NA], S[5 % NA]), rs);
+                int tu = wadd(S[4 % NA], wmul(kx, I4)) & mask;
+                int tv = wadd(S[5 % NA], wmul(kx, I5)) & mask;
+                base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
+            }
+            c = cl_light(base, lr, lg, lb);
+        }
+        a.zbuf[g] = (int)((unsigned)(k >> 32) ^ 0x80000000u);
+        a.cbuf[g] = c;
     }
 
     // counters: one atomic per wave
@@ -722,8 +976,9 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         qrows += __shfl_down(qrows, d);
     }
     if (lane == 0) {
-        if (frags) atomicAdd(&a.status->fragments, frags);
-        if (qrows) atomicAdd(&a.status->order_dependent_rows, qrows);
+        Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
+        if (frags) atomicAdd(&st->fragments, frags);
+        if (qrows) atomicAdd(&st->order_dependent_rows, qrows);
     }
 }
 
@@ -769,18 +1024,21 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
     }
 }
 
-void launch_scan(hipStream_t s, const unsigned *count, unsigned *offset, unsigned *cursor, int ntiles,
-                 unsigned long long capacity, Status *status)
+void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
+                    unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
+                    Status *status, hipEvent_t after_scan)
 {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, cursor, ntiles, capacity, status);
-}
-
-void launch_bin(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, const unsigned *offset,
-                unsigned *cursor, unsigned *list, unsigned long long capacity, Status *)
-{
-    if (np <= 0) return;
-    hipLaunchKernelGGL(bin_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, tiles_x, offset, cursor, list,
-                       capacity);
+    const bool lds = ntiles <= BIN_MAX_TILES;
+    if (np > 0) {
+        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, tiles_x, ntiles, count);
+        else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, tiles_x, count);
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned *)count, offset, cursor, ntiles, capacity, status);
+    if (after_scan) (void)hipEventRecord(after_scan, s);
+    if (np > 0) {
+        if (lds) hipLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity);
+        else hipLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, tiles_x, (const unsigned *)offset, cursor, list, capacity);
+    }
 }
 
 void launch_raster(hipStream_t s, int na, const RasterArgs &a)
