@@ -35,7 +35,7 @@ struct lt_ctx {
     uint64_t polys_in = 0;
     uint64_t list_capacity_user = 0;
     // per-submit workspace (grown on demand, reused)
-    DevBuf view, hdr, edges, list, tcount, toffset, tcursor;
+    DevBuf view, hdr, edges, prp, list, tcount, toffset, tcursor;
     DevBuf s_verts, s_polys, s_aux, s_pv;      // staging for host-pointer submits
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
@@ -148,6 +148,8 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if ((rc = ensure(c, c->hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
     if ((rc = ensure(c, c->edges, (size_t)np * emax * edge_ints(na) * sizeof(int)))) return rc;
     if ((rc = ensure(c, c->list, (size_t)capacity * sizeof(unsigned)))) return rc;
+    const bool want_prp = !screen && dim == 8;
+    if (want_prp && (rc = ensure(c, c->prp, (size_t)np * PRP_INTS * sizeof(int)))) return rc;
     if ((rc = ensure(c, c->tcount, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
     if ((rc = ensure(c, c->toffset, (size_t)(c->ntiles + 1) * sizeof(unsigned)))) return rc;
     if ((rc = ensure(c, c->tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
@@ -166,6 +168,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.W = c->W; sa.H = c->H; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.emax = emax;
     sa.hdr = (PrimHdr *)c->hdr.p; sa.edges = (int *)c->edges.p;
+    sa.prp = want_prp ? (int *)c->prp.p : nullptr;
     sa.status = c->status;
     launch_setup(c->stream, dim, screen, sa);
     if ((rc = mark(c))) return rc;
@@ -193,6 +196,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     ra.W = c->W; ra.H = c->H; ra.tiles_x = c->tiles_x; ra.tiles_y = c->tiles_y;
     ra.cbuf = c->cbuf; ra.zbuf = c->zbuf;
     ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
+    ra.prp = want_prp ? (const int *)c->prp.p : nullptr; ra.log_focus = log_focus;
     ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
     ra.status = c->status;
     launch_raster(c->stream, na, ra);
@@ -264,7 +268,7 @@ int lt_ctx_destroy(lt_ctx *c)
     if (!c) return LT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->view, &c->hdr, &c->edges, &c->list, &c->tcount, &c->toffset, &c->tcursor,
+    DevBuf *bufs[] = {&c->view, &c->hdr, &c->edges, &c->prp, &c->list, &c->tcount, &c->toffset, &c->tcursor,
                       &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -345,8 +349,8 @@ int lt_flush(lt_ctx *c)
         unsigned long long d = s.unsupported_polys - c->base.unsupported_polys;
         c->base.unsupported_polys = s.unsupported_polys;
         return fail(c, LT_ERR_UNSUPPORTED,
-                    "%llu textured polygon(s) take the reference's perspective mapper (first vertex z < 1024 or "
-                    "M_force_linear_tmapping set) or name a bad texture: not drawn", d);
+                    "%llu textured polygon(s) name a bad texture, or take the perspective mapper with a singular "
+                    "texture mapping (the reference divides by zero there) or without polyaux: not drawn", d);
     }
     if (s.order_dependent_rows > c->base.order_dependent_rows) {
         unsigned long long d = s.order_dependent_rows - c->base.order_dependent_rows;

@@ -28,6 +28,10 @@ struct PrimHdr { int yy, xx, colour, meta; };
 // wave of the setup kernel writes consecutive records, and no allocation is needed.
 __host__ __device__ constexpr int edge_ints(int na) { return na == 1 ? 4 : (na == 4 ? 12 : 16); }
 
+// Constants of G_prp_textured_polygon for one polygon (GraphicsPoly.cpp:563-578):
+// {ui, uj, uc, vi, vj, vc, zi, zj, zc, u0, v0, log_texture_scale}
+constexpr int PRP_INTS = 12;
+
 // Device status block, read back at lt_flush.  There are STATUS_SLOTS copies and a
 // workgroup adds into slot blockIdx % STATUS_SLOTS: thousands of waves adding to one
 // word would queue behind each other (one chip-wide atomic per ~12 ns on one address);
@@ -57,6 +61,7 @@ struct SetupArgs {
     int emax;                // edge slots per polygon
     PrimHdr *hdr;
     int *edges;
+    int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
     Status *status;
 };
 
@@ -72,6 +77,8 @@ struct RasterArgs {
     int W, H, tiles_x, tiles_y;
     int *cbuf, *zbuf;
     int clear_pending, clear_colour;
+    const int *prp;
+    int log_focus;
     const int *const *tex_ptr;     // device table of texture base pointers
     const int *tex_log;            // device table of log sizes
     Status *status;

@@ -200,9 +200,68 @@ __device__ __forceinline__ int persp_div(int x, int lf, int z, double rz)
     return (int)(((long long)x * ((long long)1 << lf)) / (long long)z);
 }
 
+// truncating division for any non-zero divisor through the f64 unit
+__device__ __forceinline__ int tdiv_any(int n, int d)
+{
+    const bool neg = d < 0;
+    const int q = tdivr(n, drcp(neg ? (int)(0u - (unsigned)d) : d));     // |d| <= 2^31 is exact in double
+    return neg ? (int)(0u - (unsigned)q) : q;
+}
+
+// MI_tmapping_vectors (EngBase.cpp:145-179): texture orientation vectors u, v from the
+// polygon's first three tuples (view space, before clipping).  type = m_type & M_QUAD.
+// The general case is T_linear_solve (TransBs.cpp:440-515, fixed-point branch) for the
+// 2x2 system with three right-hand sides, log_source_multiplyer = 16.  Returns false
+// where the reference would divide by zero.
+__device__ bool tmapping_vectors(int type, const Tup<8> &p1, const Tup<8> &p2, const Tup<8> &p3, int log_space,
+                                 int (&u)[3], int (&v)[3])
+{
+    if (type) {
+        if (type & 4) {        // M_QUAD_XY
+#pragma unroll
+            for (int j = 0; j < 3; j++) { u[j] = wsub(p2.v[j], p1.v[j]); v[j] = wsub(p3.v[j], p2.v[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { u[j] = wsub(p1.v[j], p2.v[j]); v[j] = wsub(p2.v[j], p3.v[j]); }
+        }
+        return true;
+    }
+    int a00 = wsub(p2.v[6], p1.v[6]) >> 16, a01 = wsub(p2.v[7], p1.v[7]) >> 16;
+    int a10 = wsub(p3.v[6], p2.v[6]) >> 16, a11 = wsub(p3.v[7], p2.v[7]) >> 16;
+    int b0[3], b1[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { b0[j] = wsub(p2.v[j], p1.v[j]); b1[j] = wsub(p3.v[j], p2.v[j]); }
+    // pivot search over column 0 (TransBs.cpp:477-481)
+    int mx = 0, num = 0;
+    { int pv = a00 >= 0 ? a00 : -a00; if (pv > mx) { mx = pv; num = 0; } }
+    { int pv = a10 >= 0 ? a10 : -a10; if (pv > mx) { mx = pv; num = 1; } }
+    if (mx != 0) {
+        if (num != 0) {
+            int t;
+            t = a00; a00 = a10; a10 = t;
+            t = a01; a01 = a11; a11 = t;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { t = b0[j]; b0[j] = b1[j]; b1[j] = t; }
+        }
+        a11 = wsub(a11, tdiv_any(wmul(a01, a10), a00));
+#pragma unroll
+        for (int j = 0; j < 3; j++) b1[j] = wsub(b1[j], tdiv_any(wmul(b0[j], a10), a00));
+    }
+    if (a11 == 0 || a00 == 0) return false;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        int x1 = tdiv_any(wshl(b1[j], log_space), a11);
+        int sum = wmul(a01, x1) >> log_space;
+        int x0 = tdiv_any(wshl(wsub(b0[j], sum), log_space), a00);
+        u[j] = x0;
+        v[j] = x1;
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------ setup
 
-constexpr int KIND_FLAT = 2, KIND_SHADED = 4, KIND_TEX_LIN = 8;
+constexpr int KIND_FLAT = 2, KIND_SHADED = 4, KIND_TEX_LIN = 8, KIND_TEX_PRP = 9;
 
 // One polygon per lane.  The stages of M_render_polygon (EngBase.cpp:379-552) and of
 // G_*_polygon up to the edge scan (GraphicsPoly.cpp:318-323) are chained as a stream:
@@ -335,6 +394,8 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     int zn = 0, xn = 0, sn = 0;       // tuples emitted by the Z stage / taken by X / taken by S
     int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
     int first_view_z = 0;             // clipped[2] of EngBase.cpp:492
+    Tup<DIM> org0 = zprev, org1 = zprev, org2 = zprev;   // original1[0..2] of EngBase.cpp:495-498 (textured only)
+    Tup<DIM> zfirst_view = zprev;                         // `clipped` tuple 0, view space
     const int wx = a.W - 1, hy = a.H - 1, xc = a.W / 2, yc = a.H / 2;
 
     // object mode: iterations 0..e read the tuples, iteration e+1 is the closing event
@@ -367,6 +428,11 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                     t.v[DIM - 1] = tx ? wshl(rec[5], 16) : 0;
                 }
             }
+            if (DIM == 8 && !SCREEN) {
+                org0 = sel(it == 0, t, org0);
+                org1 = sel(it == 1, t, org1);
+                org2 = sel(it == 2, t, org2);
+            }
             if (SCREEN) {
                 zo0 = t; zclosing0 = (it == e); cz = 1;
             } else {
@@ -394,7 +460,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
             bool closing = k == 0 && zclosing0;
             if (!SCREEN) {
                 if (!closing) {
-                    if (zn == 0) { zfirst = p; first_view_z = p.v[2]; }
+                    if (zn == 0) { zfirst = p; first_view_z = p.v[2]; if (DIM == 8) zfirst_view = p; }
                     zn++;
                     if (zn + 1 > 16) bad = true;
                 }
@@ -492,9 +558,34 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                           (long long)wsub(py[1], py[0]) * (long long)wsub(px[2], px[0]);
             if (!(c < 0)) draw = false;
         }
-        if (draw && kind == KIND_TEX_LIN && (a.force_linear || first_view_z < 1024)) {
-            // EngBase.cpp:491-493 routes this polygon to the perspective mapper
-            unsupported = true; draw = false;
+        if (DIM == 8 && draw && kind == KIND_TEX_LIN && (a.force_linear || first_view_z < 1024)) {
+            // EngBase.cpp:491-506 routes this polygon to the perspective mapper
+            const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
+            const int log_space = ax.w >> 8;
+            int u[3], v[3];
+            Tup<8> q0, q1, q2, O;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { q0.v[j] = org0.v[j % DIM]; q1.v[j] = org1.v[j % DIM]; q2.v[j] = org2.v[j % DIM]; O.v[j] = zfirst_view.v[j % DIM]; }
+            if (!a.prp || log_space < 0 || log_space > 24 || !tmapping_vectors(ax.w & 0x0c, q0, q1, q2, log_space, u, v)) {
+                unsupported = true; draw = false;
+            } else {
+                kind = KIND_TEX_PRP;
+                // GraphicsPoly.cpp:563-578
+                const int x0 = O.v[0], y0 = O.v[1], z0 = O.v[2];
+                int *pr = a.prp + (size_t)poly * PRP_INTS;
+                int4 c0, c1, c2;
+                c0.x = wsub(wmul(v[2], y0), wmul(v[1], z0));      // ui
+                c0.y = wsub(wmul(v[0], z0), wmul(v[2], x0));      // uj
+                c0.z = wsub(wmul(v[1], x0), wmul(v[0], y0));      // uc
+                c0.w = wsub(wmul(u[1], z0), wmul(u[2], y0));      // vi
+                c1.x = wsub(wmul(u[2], x0), wmul(u[0], z0));      // vj
+                c1.y = wsub(wmul(u[0], y0), wmul(u[1], x0));      // vc
+                c1.z = wsub(wmul(v[1], u[2]), wmul(v[2], u[1]));  // zi
+                c1.w = wsub(wmul(v[2], u[0]), wmul(v[0], u[2]));  // zj
+                c2.x = wsub(wmul(v[0], u[1]), wmul(v[1], u[0]));  // zc
+                c2.y = O.v[6]; c2.z = O.v[7]; c2.w = log_space;
+                ((int4 *)pr)[0] = c0; ((int4 *)pr)[1] = c1; ((int4 *)pr)[2] = c2;
+            }
         }
     }
     if (ne > a.emax) { bad = true; draw = false; }
@@ -952,6 +1043,46 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
             int lg = wadd(S[2 % NA], wmul(kx, I2)) >> 16;
             int lb = wadd(S[3 % NA], wmul(kx, I3)) >> 16;
             int base = h.z;
+            if (NA == 6 && kind == KIND_TEX_PRP) {
+                // G_prp_textured_polygon, GraphicsPoly.cpp:592-640: exact texture
+                // coordinates at the ends of 32-pixel runs, linear in between
+                if ((I1 | I2 | I3) != 0) qrows++;
+                const int4 c0 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[0];
+                const int4 c1 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[1];
+                const int4 c2 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[2];
+                const int lf = a.log_focus, lsc = c2.w;
+                const int begp = beg - a.W / 2, endp = end - a.W / 2, xp = gx - a.W / 2, yp = gy - a.H / 2;
+                const int xx = wadd(wmul(yp, c0.y) >> lf, c0.z), yy = wadd(wmul(yp, c1.x) >> lf, c1.y);
+                const int zz = wadd(wmul(yp, c1.w) >> lf, c2.x);
+                const int d = xp - begp;
+                int xs, q;                                   // run start boundary, pixel offset in the run
+                if (d <= 32) { xs = begp; q = d; }
+                else { const int k32 = ((d - 1) >> 5) << 5; xs = begp + k32; q = xp - xs - 1; }
+                int xe = xs + 32;
+                if (xe > endp) xe = endp;
+                const int rspan = d <= 32 ? xe - xs : xe - xs - 1;
+                int t0u = 0, t0v = 0, t1u = 0, t1v = 0;
+                {
+                    const int zzz = wadd(zz, wmul(xs, c1.z) >> lf);
+                    if (zzz != 0) {
+                        t0u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xs, c0.x) >> lf), lsc), zzz), 16), c2.y);
+                        t0v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xs, c0.w) >> lf), lsc), zzz), 16), c2.z);
+                    }
+                }
+                {
+                    const int zzz = wadd(zz, wmul(xe, c1.z) >> lf);
+                    if (zzz != 0) {
+                        t1u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xe, c0.x) >> lf), lsc), zzz), 16), c2.y);
+                        t1v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xe, c0.w) >> lf), lsc), zzz), 16), c2.z);
+                    }
+                }
+                int iu = 0, iv = 0;
+                if (rspan != 0) { const double rr = drcp(rspan); iu = tdivr(wsub(t1u, t0u), rr); iv = tdivr(wsub(t1v, t0v), rr); }
+                const int lg2 = a.tex_log[ptex];
+                const int mask = wsub(wshl(1, lg2 + 16), 1);
+                const int tu = wadd(t0u, wmul(q, iu)) & mask, tv = wadd(t0v, wmul(q, iv)) & mask;
+                base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
+            }
             if (NA == 6 && kind == KIND_TEX_LIN) {
                 // GraphicsPoly.cpp:443-446,465,486: wrap, then fetch the texel
                 if ((I1 | I2 | I3) != 0) qrows++;

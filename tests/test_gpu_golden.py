@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 FRAMES = GU.frames()
 # scenes that need parts of the reference this library does not draw yet: they must be
 # refused with LT_ERR_UNSUPPORTED, never drawn approximately without saying so
-NEEDS_PRP_OR_ORDER = ["fuzz160x120-rt8-*", "c3mix-*", "c3q2-*", "c3lin-*"]
+NEEDS_PRP_OR_ORDER = ["fuzz160x120-rt8-*", "c3q2-*"]
 
 
 def _unsupported(name):

@@ -44,16 +44,41 @@ def test_fuzz_polys_small_screen(env, rt, seed):
     assert gc["polys_drawn"] == ocn["polys_drawn"]
 
 
+@pytest.mark.parametrize("zrange", [(1100, 3000), (12, 900)], ids=["linear-mapper", "perspective-mapper"])
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_lin_textured_equal_lights(env, seed):
+def test_fuzz_textured_equal_lights(env, seed, zrange):
+    """Textured polygons with one light value per polygon: far ones take
+    G_lin_textured_polygon, near ones (first clipped vertex z < 1024, EngBase.cpp:491-493)
+    G_prp_textured_polygon with MI_tmapping_vectors / T_linear_solve."""
     P, G = env
     sc = S.gen_fuzz_polys(80, 160, 120, 7, 500 + seed, render_type=S.M_TEXTURED, textured=True,
-                          equal_lights=True, zrange=(1100, 3000))
-    # keep every polygon on the linear mapper: first vertex z >= 1024 (EngBase.cpp:491-493)
-    firsts = sc.polyverts[sc.polys[:, 3], 0]
-    sc.verts[firsts, 2] = np.maximum(sc.verts[firsts, 2], 1024)
+                          equal_lights=True, zrange=zrange)
     c, z, oc, oz, gc, ocn = _render_both(P, G, sc)
+    assert ocn["unsupported"] == 0
     assert (z == oz).all() and (c == oc).all()
+    assert gc["fragments"] == ocn["fragments"]
+
+
+def test_c3_clipped_textured_4k_subset(env):
+    """30k clipped textured triangles at 4K.  One of them has a singular texture mapping
+    (T_linear_solve would divide by zero, TransBs.cpp:505: the reference crashes there);
+    both the checker and the HIP path skip it and say so."""
+    P, G = env
+    sc = S.gen_c3(30000, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=90)
+    ctx = G.Context(sc.width, sc.height)
+    orc = P.Oracle(sc.width, sc.height)
+    orc.set_texture(0, *sc.textures[0])
+    orc.clear(0, 0, 0, 0)
+    orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type, sc.log_focus)
+    ctx.clear(0)
+    ctx.submit_scene(sc)
+    with pytest.raises(G.LtError) as ei:
+        ctx.flush()
+    assert ei.value.code == -5
+    c, z = ctx.readback()
+    gc, ocn = ctx.counters(), orc.counters()
+    assert gc["unsupported_polys"] == ocn["unsupported"] == 1
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
     assert gc["fragments"] == ocn["fragments"]
 
 
