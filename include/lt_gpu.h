@@ -83,6 +83,19 @@ int lt_set_stream(lt_ctx *ctx, void *hip_stream);
  * (64 per polygon, at least 1M). */
 int lt_set_list_capacity(lt_ctx *ctx, uint64_t refs);
 
+/* The reference's textured fills advance the light accumulators only where the depth
+ * test passes (GraphicsPoly.cpp:485-493, 666-674), so with a light gradient along a span
+ * a pixel's colour depends on the draw history of its row.  LT_ORDER_AUTO (default):
+ * a textured batch in which some drawn polygon has differing vertex lights is filled by
+ * the draw-order kernel (exact, slower), any other batch by the tile kernel.
+ * LT_ORDER_ALWAYS: every textured batch takes the draw-order kernel.  LT_ORDER_NEVER:
+ * the tile kernel always; affected pixels are counted and lt_flush reports
+ * LT_ERR_UNSUPPORTED. */
+#define LT_ORDER_AUTO    0
+#define LT_ORDER_ALWAYS  1
+#define LT_ORDER_NEVER   2
+int lt_set_textured_order(lt_ctx *ctx, int mode);
+
 /* --- framebuffer --------------------------------------------------------------- */
 
 /* G_clear (GraphicsBase.cpp:99-111) with the lit colour already computed

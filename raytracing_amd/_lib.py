@@ -13,7 +13,7 @@ EXPORTS = [
     "lt_ctx_create", "lt_ctx_destroy", "lt_last_error", "lt_set_stream", "lt_set_list_capacity",
     "lt_clear", "lt_flush", "lt_readback", "lt_framebuffer", "lt_get_counters", "lt_reset_counters",
     "lt_texture_upload", "lt_transform", "lt_submit_object", "lt_submit_object_dev",
-    "lt_submit_screen_polys", "lt_set_profiling", "lt_get_stage_ms",
+    "lt_submit_screen_polys", "lt_set_profiling", "lt_get_stage_ms", "lt_set_textured_order",
 ]
 
 
@@ -58,6 +58,7 @@ def lib():
     L.lt_submit_object_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
     L.lt_submit_screen_polys.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.lt_set_profiling.argtypes = [vp, i32]
+    L.lt_set_textured_order.argtypes = [vp, i32]
     L.lt_get_stage_ms.argtypes = [vp, C.POINTER(C.c_double * 5), C.POINTER(i32)]
     for name in EXPORTS:
         if name != "lt_last_error":

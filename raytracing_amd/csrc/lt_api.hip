@@ -34,6 +34,8 @@ struct lt_ctx {
     Status base{};                     // host copy at the last reset
     uint64_t polys_in = 0;
     uint64_t list_capacity_user = 0;
+    int order_mode = 0;                // LT_ORDER_AUTO / ALWAYS / NEVER
+    int *order_flag = nullptr;         // device
     // per-submit workspace (grown on demand, reused)
     DevBuf view, hdr, edges, prp, list, tcount, toffset, tcursor;
     DevBuf s_verts, s_polys, s_aux, s_pv;      // staging for host-pointer submits
@@ -155,6 +157,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if ((rc = ensure(c, c->tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
 
     HIPCHK(c, hipMemsetAsync(c->tcount.p, 0, (size_t)c->ntiles * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->order_flag, (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0, 4, c->stream));
     if (screen) { if ((rc = mark(c))) return rc; if ((rc = mark(c))) return rc; }   // no transform stage
     // (object mode: lt_submit_object_dev has recorded the marks around the transform)
 
@@ -169,6 +172,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.emax = emax;
     sa.hdr = (PrimHdr *)c->hdr.p; sa.edges = (int *)c->edges.p;
     sa.prp = want_prp ? (int *)c->prp.p : nullptr;
+    sa.order_flag = c->order_flag; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
     sa.status = c->status;
     launch_setup(c->stream, dim, screen, sa);
     if ((rc = mark(c))) return rc;
@@ -198,8 +202,10 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
     ra.prp = want_prp ? (const int *)c->prp.p : nullptr; ra.log_focus = log_focus;
     ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
+    ra.order_flag = c->order_flag;
     ra.status = c->status;
     launch_raster(c->stream, na, ra);
+    if (dim == 8 && c->order_mode != LT_ORDER_NEVER) HIPCHK(c, launch_ordered(c->stream, ra));
     if ((rc = mark(c))) return rc;
     HIPCHK(c, hipGetLastError());
 
@@ -253,6 +259,8 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     CREATECHK(hipMalloc((void **)&c->zbuf, n * sizeof(int)));
     CREATECHK(hipMalloc((void **)&c->status, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMemset(c->status, 0, sizeof(Status) * STATUS_SLOTS));
+    CREATECHK(hipMalloc((void **)&c->order_flag, 256));
+    CREATECHK(hipMemset(c->order_flag, 0, 256));
     CREATECHK(hipMalloc((void **)&c->tex_ptr_d, sizeof(int *) * LT_MAX_TEXTURES));
     CREATECHK(hipMalloc((void **)&c->tex_log_d, sizeof(int) * LT_MAX_TEXTURES));
     CREATECHK(hipMemset((void *)c->tex_ptr_d, 0, sizeof(int *) * LT_MAX_TEXTURES));
@@ -278,6 +286,7 @@ int lt_ctx_destroy(lt_ctx *c)
     if (c->zbuf) (void)hipFree(c->zbuf);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->status) (void)hipFree(c->status);
+    if (c->order_flag) (void)hipFree(c->order_flag);
     if (c->tex_ptr_d) (void)hipFree((void *)c->tex_ptr_d);
     if (c->tex_log_d) (void)hipFree(c->tex_log_d);
     delete c;
@@ -293,6 +302,13 @@ int lt_set_stream(lt_ctx *c, void *hip_stream)
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->stream = (hipStream_t)hip_stream;
+    return LT_OK;
+}
+
+int lt_set_textured_order(lt_ctx *c, int mode)
+{
+    if (!c || mode < LT_ORDER_AUTO || mode > LT_ORDER_NEVER) return fail(c, LT_ERR_ARG, "lt_set_textured_order: mode %d", mode);
+    c->order_mode = mode;
     return LT_OK;
 }
 
@@ -356,8 +372,9 @@ int lt_flush(lt_ctx *c)
         unsigned long long d = s.order_dependent_rows - c->base.order_dependent_rows;
         c->base.order_dependent_rows = s.order_dependent_rows;
         return fail(c, LT_ERR_UNSUPPORTED,
-                    "%llu textured row(s) have a light gradient: the reference advances light only on depth-test "
-                    "passes there, which depends on draw history; drawn as if every earlier pixel had passed", d);
+                    "%llu textured pixel(s) lie on rows with a light gradient while LT_ORDER_NEVER is set: the "
+                    "reference advances light only on depth-test passes there; drawn as if every earlier pixel "
+                    "had passed", d);
     }
     return LT_OK;
 }

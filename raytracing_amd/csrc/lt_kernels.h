@@ -61,6 +61,8 @@ struct SetupArgs {
     int emax;                // edge slots per polygon
     PrimHdr *hdr;
     int *edges;
+    int *order_flag;         // device word raised when a textured polygon's vertex lights differ
+    int detect_order;
     int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
     Status *status;
 };
@@ -79,6 +81,7 @@ struct RasterArgs {
     int clear_pending, clear_colour;
     const int *prp;
     int log_focus;
+    const int *order_flag;   // see ordered_kernel
     const int *const *tex_ptr;     // device table of texture base pointers
     const int *tex_log;            // device table of log sizes
     Status *status;
@@ -91,6 +94,7 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int 
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
                     Status *status, hipEvent_t after_scan);
 void launch_raster(hipStream_t s, int na, const RasterArgs &a);
+hipError_t launch_ordered(hipStream_t s, const RasterArgs &a);   // textured batches only
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 
 }  // namespace lt

@@ -393,6 +393,8 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     zprev = Tup<DIM>(); zfirst = zprev; xprev = zprev; sprev = zprev; sfirst = zprev;
     int zn = 0, xn = 0, sn = 0;       // tuples emitted by the Z stage / taken by X / taken by S
     int px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+    bool lights_vary = false;         // textured: vertex lights differ (the fill is then order dependent)
+    int l0r = 0, l0g = 0, l0b = 0;
     int first_view_z = 0;             // clipped[2] of EngBase.cpp:492
     Tup<DIM> org0 = zprev, org1 = zprev, org2 = zprev;   // original1[0..2] of EngBase.cpp:495-498 (textured only)
     Tup<DIM> zfirst_view = zprev;                         // `clipped` tuple 0, view space
@@ -427,6 +429,10 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                     t.v[DIM - 2] = tx ? wshl(rec[4], 16) : 0;
                     t.v[DIM - 1] = tx ? wshl(rec[5], 16) : 0;
                 }
+            }
+            if (DIM == 8) {
+                if (it == 0) { l0r = t.v[3]; l0g = t.v[4]; l0b = t.v[5]; }
+                else lights_vary = lights_vary || t.v[3] != l0r || t.v[4] != l0g || t.v[5] != l0b;
             }
             if (DIM == 8 && !SCREEN) {
                 org0 = sel(it == 0, t, org0);
@@ -605,6 +611,11 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
         hdr.meta = ne | (kind << 8) | ((tex < 0 ? 0 : tex) << 16);
     }
     ((int4 *)a.hdr)[poly] = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
+    if (DIM == 8 && a.detect_order) {
+        const bool ord = draw && lights_vary && kind >= KIND_TEX_LIN;
+        const unsigned long long om = __ballot(ord);
+        if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = 1;
+    }
 
     // counters: one atomic per wave, spread over the status slots
     Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
@@ -885,6 +896,155 @@ __device__ __forceinline__ bool depth_row_mem(const int *__restrict__ edges, int
     return true;
 }
 
+// Colour of the pixel (gx, gy) of a polygon row [beg, end] with start values S and
+// per-pixel increments I (GraphicsPoly.cpp:372 shaded, :465-491 linear texture,
+// :592-675 perspective texture).  `kl` is the number of increments the light
+// accumulators have taken when this pixel is drawn: gx - beg for the shaded fill, the
+// number of earlier pixels of the span that passed the depth test for the textured
+// fills (GraphicsPoly.cpp:485-493, 666-674).
+template <int NA>
+__device__ __forceinline__ int pixel_colour(const RasterArgs &a, const int4 h, int poly, int gx, int gy, int beg,
+                                            int end, const int (&S)[NA], const int (&I)[NA], int kl)
+{
+    const int kind = (h.w >> 8) & 0xff, ptex = (h.w >> 16) & 0xff;
+    const int kx = gx - beg;
+    const int lr = wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16;
+    const int lg = wadd(S[2 % NA], wmul(kl, I[2 % NA])) >> 16;
+    const int lb = wadd(S[3 % NA], wmul(kl, I[3 % NA])) >> 16;
+    int base = h.z;
+    if (NA == 6 && kind == KIND_TEX_PRP) {
+        // exact texture coordinates at the ends of 32-pixel runs, linear in between
+        const int4 c0 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[0];
+        const int4 c1 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[1];
+        const int4 c2 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[2];
+        const int lf = a.log_focus, lsc = c2.w;
+        const int begp = beg - a.W / 2, endp = end - a.W / 2, xp = gx - a.W / 2, yp = gy - a.H / 2;
+        const int xx = wadd(wmul(yp, c0.y) >> lf, c0.z), yy = wadd(wmul(yp, c1.x) >> lf, c1.y);
+        const int zz = wadd(wmul(yp, c1.w) >> lf, c2.x);
+        const int d = xp - begp;
+        int xs, q;                                   // run start boundary, pixel offset in the run
+        if (d <= 32) { xs = begp; q = d; }
+        else { const int k32 = ((d - 1) >> 5) << 5; xs = begp + k32; q = xp - xs - 1; }
+        int xe = xs + 32;
+        if (xe > endp) xe = endp;
+        const int rspan = d <= 32 ? xe - xs : xe - xs - 1;
+        int t0u = 0, t0v = 0, t1u = 0, t1v = 0;
+        {
+            const int zzz = wadd(zz, wmul(xs, c1.z) >> lf);
+            if (zzz != 0) {
+                t0u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xs, c0.x) >> lf), lsc), zzz), 16), c2.y);
+                t0v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xs, c0.w) >> lf), lsc), zzz), 16), c2.z);
+            }
+        }
+        {
+            const int zzz = wadd(zz, wmul(xe, c1.z) >> lf);
+            if (zzz != 0) {
+                t1u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xe, c0.x) >> lf), lsc), zzz), 16), c2.y);
+                t1v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xe, c0.w) >> lf), lsc), zzz), 16), c2.z);
+            }
+        }
+        int iu = 0, iv = 0;
+        if (rspan != 0) { const double rr = drcp(rspan); iu = tdivr(wsub(t1u, t0u), rr); iv = tdivr(wsub(t1v, t0v), rr); }
+        const int lg2 = a.tex_log[ptex];
+        const int mask = wsub(wshl(1, lg2 + 16), 1);
+        const int tu = wadd(t0u, wmul(q, iu)) & mask, tv = wadd(t0v, wmul(q, iv)) & mask;
+        base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
+    }
+    if (NA == 6 && kind == KIND_TEX_LIN) {
+        // GraphicsPoly.cpp:443-446,465,486: wrap, then fetch the texel
+        const int lg2 = a.tex_log[ptex];
+        const int mask = wsub(wshl(1, lg2 + 16), 1);
+        const int tu = wadd(S[4 % NA], wmul(kx, I[4 % NA])) & mask;
+        const int tv = wadd(S[5 % NA], wmul(kx, I[5 % NA])) & mask;
+        base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
+    }
+    return cl_light(base, lr, lg, lb);
+}
+
+// Draw-order fill for textured batches whose light varies along spans.  There the
+// reference advances the light accumulators only where the depth test passes
+// (GraphicsPoly.cpp:485-493, 666-674), so a pixel's colour depends on what every earlier
+// polygon left in the depth buffer along the same row.  Rows do not interact, so a
+// workgroup owns a band of full-width rows (depth and colour in LDS), each wave owns
+// every fourth row of the band, and each wave walks ALL polygons in draw order: it reads
+// headers 64 at a time, keeps those that touch the band (ballot), and sweeps each of
+// their rows 64 pixels per step -- depth test, ballot, prefix count of the passes, colour.
+// No lists and no atomics: the order is the array order.  Runs only if the setup kernel
+// raised *order_flag; the tile kernel then returns at once.
+template <int NA>
+__global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
+{
+    extern __shared__ int band_lds[];
+    if (!*a.order_flag) return;
+    const int W = a.W;
+    int *zt = band_lds, *ct = band_lds + R * W;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int y0 = blockIdx.x * R, y1 = min(y0 + R, a.H);
+    const int npx = (y1 - y0) * W;
+    for (int p = t; p < npx; p += 256) {
+        const size_t g = (size_t)y0 * W + p;
+        zt[p] = a.clear_pending ? INT_MAX : a.zbuf[g];
+        ct[p] = a.clear_pending ? a.clear_colour : a.cbuf[g];
+    }
+    __syncthreads();
+
+    unsigned long long frags = 0;
+    for (int base = 0; base < a.np; base += 64) {
+        const int mypoly = base + lane;
+        int4 h = make_int4(0, 0, 0, 0);
+        if (mypoly < a.np) h = ((const int4 *)a.hdr)[mypoly];
+        const bool ov = (h.w & 0xff) != 0 && (h.x & 0xffff) < y1 && ((h.x >> 16) & 0xffff) > y0;
+        unsigned long long mask = __ballot(ov);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int4 bh = make_int4(__shfl(h.x, src), __shfl(h.y, src), __shfl(h.z, src), __shfl(h.w, src));
+            const int poly = base + src;
+            const int ne = bh.w & 0xff, kind = (bh.w >> 8) & 0xff;
+            const int ra = max(bh.x & 0xffff, y0), rb = min((bh.x >> 16) & 0xffff, y1);
+            // first row of this wave (rows y0+wv, y0+wv+4, ...) at or after ra
+            int y = y0 + wv + (((ra - y0 - wv + 3) >> 2) << 2);
+            if (ra - y0 < wv) y = y0 + wv;
+            for (; y < rb; y += 4) {
+                int S[NA], E[NA], I[NA], beg = 0, end = 0;
+                if (!row_ends<NA>(a.edges, a.np, poly, ne, y, beg, end, S, E)) continue;
+                int span = end - beg;
+                if (span == 0) span = 1;
+                const double rs = drcp(span);
+#pragma unroll
+                for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+                if (lane == 0) frags += (unsigned long long)(end - beg + 1);
+                int *zrow = zt + (y - y0) * W, *crow = ct + (y - y0) * W;
+                int carry = 0;
+                for (int xb = beg; xb <= end; xb += 64) {
+                    const int x = xb + lane;
+                    const bool in = x <= end;
+                    const int k = x - beg;
+                    const int zi = wadd(S[0], wmul(k, I[0])) >> 16;
+                    const bool pass = in && zrow[x < W ? x : W - 1] > zi;
+                    const unsigned long long pm = __ballot(pass);
+                    if (pass) {
+                        const int nb = carry + __popcll(pm & ((1ull << lane) - 1ull));
+                        int c = bh.z;
+                        if (NA > 1 && kind != KIND_FLAT)
+                            c = pixel_colour<NA>(a, bh, poly, x, y, beg, end, S, I, kind >= KIND_TEX_LIN ? nb : k);
+                        zrow[x] = zi;
+                        crow[x] = c;
+                    }
+                    carry += __popcll(pm);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = t; p < npx; p += 256) {
+        const size_t g = (size_t)y0 * W + p;
+        a.zbuf[g] = zt[p];
+        a.cbuf[g] = ct[p];
+    }
+    if (lane == 0 && frags) atomicAdd(&(a.status + (blockIdx.x % STATUS_SLOTS))->fragments, frags);
+}
+
 // One workgroup per screen tile; LDS holds the tile's packed (depth, draw index) keys.
 //
 // Depth pass.  Lanes take the tile's polygons one each.  A polygon that is small inside
@@ -915,6 +1075,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     if ((unsigned long long)lbeg + lcnt > a.list_capacity)      // list overflow (reported by the scan): stay inside the list
         lcnt = a.list_capacity > lbeg ? (unsigned)(a.list_capacity - lbeg) : 0u;
     if (lcnt == 0 && !a.clear_pending) return;       // untouched tile of a frame that is already in HBM
+    if (NA == 6 && *a.order_flag) return;            // the draw-order kernel fills this batch
 
     // ---- tile in: depth only
     for (int p = t; p < TW * TH; p += RASTER_THREADS) {
@@ -1030,71 +1191,15 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff, ptex = (h.w >> 16) & 0xff;
         int c = h.z;
         if (NA > 1 && kind != KIND_FLAT) {
-            int S[NA], E[NA], beg = 0, end = 0;
+            int S[NA], E[NA], I[NA], beg = 0, end = 0;
             row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E);
             int span = end - beg;
             if (span == 0) span = 1;
-            const int kx = gx - beg;
             const double rs = drcp(span);
-            int I1 = tdivr(wsub(E[1 % NA], S[1 % NA]), rs);
-            int I2 = tdivr(wsub(E[2 % NA], S[2 % NA]), rs);
-            int I3 = tdivr(wsub(E[3 % NA], S[3 % NA]), rs);
-            int lr = wadd(S[1 % NA], wmul(kx, I1)) >> 16;
-            int lg = wadd(S[2 % NA], wmul(kx, I2)) >> 16;
-            int lb = wadd(S[3 % NA], wmul(kx, I3)) >> 16;
-            int base = h.z;
-            if (NA == 6 && kind == KIND_TEX_PRP) {
-                // G_prp_textured_polygon, GraphicsPoly.cpp:592-640: exact texture
-                // coordinates at the ends of 32-pixel runs, linear in between
-                if ((I1 | I2 | I3) != 0) qrows++;
-                const int4 c0 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[0];
-                const int4 c1 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[1];
-                const int4 c2 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[2];
-                const int lf = a.log_focus, lsc = c2.w;
-                const int begp = beg - a.W / 2, endp = end - a.W / 2, xp = gx - a.W / 2, yp = gy - a.H / 2;
-                const int xx = wadd(wmul(yp, c0.y) >> lf, c0.z), yy = wadd(wmul(yp, c1.x) >> lf, c1.y);
-                const int zz = wadd(wmul(yp, c1.w) >> lf, c2.x);
-                const int d = xp - begp;
-                int xs, q;                                   // run start boundary, pixel offset in the run
-                if (d <= 32) { xs = begp; q = d; }
-                else { const int k32 = ((d - 1) >> 5) << 5; xs = begp + k32; q = xp - xs - 1; }
-                int xe = xs + 32;
-                if (xe > endp) xe = endp;
-                const int rspan = d <= 32 ? xe - xs : xe - xs - 1;
-                int t0u = 0, t0v = 0, t1u = 0, t1v = 0;
-                {
-                    const int zzz = wadd(zz, wmul(xs, c1.z) >> lf);
-                    if (zzz != 0) {
-                        t0u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xs, c0.x) >> lf), lsc), zzz), 16), c2.y);
-                        t0v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xs, c0.w) >> lf), lsc), zzz), 16), c2.z);
-                    }
-                }
-                {
-                    const int zzz = wadd(zz, wmul(xe, c1.z) >> lf);
-                    if (zzz != 0) {
-                        t1u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xe, c0.x) >> lf), lsc), zzz), 16), c2.y);
-                        t1v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xe, c0.w) >> lf), lsc), zzz), 16), c2.z);
-                    }
-                }
-                int iu = 0, iv = 0;
-                if (rspan != 0) { const double rr = drcp(rspan); iu = tdivr(wsub(t1u, t0u), rr); iv = tdivr(wsub(t1v, t0v), rr); }
-                const int lg2 = a.tex_log[ptex];
-                const int mask = wsub(wshl(1, lg2 + 16), 1);
-                const int tu = wadd(t0u, wmul(q, iu)) & mask, tv = wadd(t0v, wmul(q, iv)) & mask;
-                base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
-            }
-            if (NA == 6 && kind == KIND_TEX_LIN) {
-                // GraphicsPoly.cpp:443-446,465,486: wrap, then fetch the texel
-                if ((I1 | I2 | I3) != 0) qrows++;
-                const int lg2 = a.tex_log[ptex];
-                const int mask = wsub(wshl(1, lg2 + 16), 1);
-                int I4 = tdivr(wsub(E[4 % NA], S[4 % NA]), rs);
-                int I5 = tdivr(wsub(E[5 % NA], S[5 % NA]), rs);
-                int tu = wadd(S[4 % NA], wmul(kx, I4)) & mask;
-                int tv = wadd(S[5 % NA], wmul(kx, I5)) & mask;
-                base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
-            }
-            c = cl_light(base, lr, lg, lb);
+#pragma unroll
+            for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+            if (NA == 6 && kind >= KIND_TEX_LIN && ((I[1 % NA] | I[2 % NA] | I[3 % NA]) != 0)) qrows++;
+            c = pixel_colour<NA>(a, h, poly, gx, gy, beg, end, S, I, gx - beg);
         }
         a.zbuf[g] = (int)((unsigned)(k >> 32) ^ 0x80000000u);
         a.cbuf[g] = c;
@@ -1178,6 +1283,29 @@ void launch_raster(hipStream_t s, int na, const RasterArgs &a)
     if (na == 1) hipLaunchKernelGGL((raster_kernel<1>), g, b, 0, s, a);
     else if (na == 4) hipLaunchKernelGGL((raster_kernel<4>), g, b, 0, s, a);
     else hipLaunchKernelGGL((raster_kernel<6>), g, b, 0, s, a);
+}
+
+int ordered_band_rows(int W, int H)
+{
+    int r = (120 * 1024) / (8 * W);
+    if (r < 1) r = 1;
+    if (r > 16) r = 16;
+    if (r > H) r = H;
+    return r;
+}
+
+hipError_t launch_ordered(hipStream_t s, const RasterArgs &a)
+{
+    const int R = ordered_band_rows(a.W, a.H);
+    const size_t lds = (size_t)R * a.W * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)ordered_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((ordered_kernel<6>), dim3((a.H + R - 1) / R), dim3(256), lds, s, a, R);
+    return hipSuccess;
 }
 
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour)

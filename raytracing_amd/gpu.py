@@ -90,6 +90,10 @@ class Context:
     def reset_counters(self):
         self._chk(self.L.lt_reset_counters(self.h_ctx))
 
+    def set_textured_order(self, mode):
+        """0 auto, 1 always the draw-order kernel for textured batches, 2 never"""
+        self._chk(self.L.lt_set_textured_order(self.h_ctx, mode))
+
     def set_profiling(self, on):
         self._chk(self.L.lt_set_profiling(self.h_ctx, int(on)))
 

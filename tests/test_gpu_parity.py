@@ -59,6 +59,25 @@ def test_fuzz_textured_equal_lights(env, seed, zrange):
     assert gc["fragments"] == ocn["fragments"]
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_textured_varying_lights(env, seed):
+    """Light gradients along textured spans: the pass-count dependent light of
+    GraphicsPoly.cpp:485-493 / 666-674, through the draw-order kernel."""
+    P, G = env
+    sc = S.gen_fuzz_polys(80, 160, 120, 7, 900 + seed, render_type=S.M_TEXTURED, textured=True,
+                          equal_lights=False, zrange=(12, 2000))
+    c, z, oc, oz, gc, ocn = _render_both(P, G, sc)
+    assert (z == oz).all() and (c == oc).all()
+    assert gc["fragments"] == ocn["fragments"]
+
+
+def test_c3_varying_lights_1080p(env):
+    P, G = env
+    sc = S.gen_c3(20000, 1920, 1080, 10, radius=12, equal_lights=False, lin_percent=100, seed=0xC0FFEE43)
+    c, z, oc, oz, gc, ocn = _render_both(P, G, sc)
+    assert (z == oz).all() and (c == oc).all()
+
+
 def test_c3_clipped_textured_4k_subset(env):
     """30k clipped textured triangles at 4K.  One of them has a singular texture mapping
     (T_linear_solve would divide by zero, TransBs.cpp:505: the reference crashes there);
