@@ -1,0 +1,354 @@
+// Host mirror of the reference's polygon-path API over the C-ABI (see lt_engine.h).
+// Matrix set-up stays on the host, as in the reference (it is a few dozen integer
+// multiplies per object); everything per vertex, per polygon and per pixel goes to the GPU.
+#include "lt_engine.h"
+#include "../../include/lt_gpu.h"
+
+#include <limits.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <vector>
+
+// ------------------------------------------------------------------ state
+
+HW_pixel *G_c_buffer = nullptr;
+int *G_z_buffer = nullptr;
+long G_c_buffer_size = 0;
+int M_force_linear_tmapping = 0;                     // EngBase.cpp:36
+int M_camera_x, M_camera_y, M_camera_z, M_camera_log_focus;
+
+namespace {
+
+int g_w = 600, g_h = 600;                            // the reference's compile-time size, LightTrack.h:44-45
+int g_device = 0;
+lt_ctx *g_ctx = nullptr;
+int g_rendering_type = 0;
+bool g_host_frame_current = false;
+
+int T_sin_tab[256], T_cos_tab[256];
+int Ts[9], Tw[9], Tc[12];                            // self / world rotation, concatenated transform
+int Cb[4] = {0, 0, 0, 0};                            // clip window
+
+// queued draws: consecutive calls of one kind form one batch
+enum QKind { Q_NONE, Q_SCREEN, Q_VIEW };
+QKind q_kind = Q_NONE;
+int q_type = 0;                                      // LT_FLAT / LT_SHADED / LT_TEXTURED
+int q_focus = 0, q_force = 0;
+std::vector<int32_t> q_tuples, q_desc;               // Q_SCREEN
+std::vector<int32_t> q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
+int q_max_edges = 0;
+std::map<const void *, int> g_tex_handles;           // texel pointer -> handle
+int g_next_tex = 0;
+
+inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+inline int fx(int a, int b) { return wmul(a, b) >> T_P; }
+
+void chk(int rc)
+{
+    if (rc != LT_OK) {
+        char buf[600];
+        snprintf(buf, sizeof buf, "(GPU) %s", lt_last_error(g_ctx));
+        HW_error(buf);
+    }
+}
+
+void need_ctx()
+{
+    if (!g_ctx) HW_error((char *)"(Graphics) G_init_graphics has not been called.\n");
+}
+
+int texture_handle(HW_pixel *texels, int log_size)
+{
+    auto it = g_tex_handles.find(texels);
+    if (it != g_tex_handles.end()) return it->second;
+    if (g_next_tex >= LT_MAX_TEXTURES) HW_error((char *)"(GPU) too many textures.\n");
+    int h = g_next_tex++;
+    chk(lt_texture_upload(g_ctx, h, texels, log_size));
+    g_tex_handles[texels] = h;
+    return h;
+}
+
+void run_queue()
+{
+    if (q_kind == Q_SCREEN && !q_desc.empty()) {
+        int dim = q_type == LT_FLAT ? 3 : (q_type == LT_SHADED ? 6 : 8);
+        chk(lt_submit_screen_polys(g_ctx, q_type, q_tuples.data(), (int)(q_tuples.size() / dim), q_desc.data(),
+                                   (int)(q_desc.size() / 4), q_max_edges));
+    } else if (q_kind == Q_VIEW && !q_polys.empty()) {
+        chk(lt_submit_object(g_ctx, nullptr, q_verts.data(), (int)(q_verts.size() / 4), q_polys.data(), q_aux.data(),
+                             (int)(q_polys.size() / 4), q_pv.data(), (int)(q_pv.size() / 6), q_type, q_focus, q_force,
+                             q_max_edges));
+    }
+    q_kind = Q_NONE;
+    q_tuples.clear(); q_desc.clear(); q_verts.clear(); q_polys.clear(); q_aux.clear(); q_pv.clear();
+    q_max_edges = 0;
+}
+
+void open_queue(QKind kind, int type)
+{
+    if (q_kind != kind || q_type != type || (kind == Q_VIEW && (q_focus != M_camera_log_focus || q_force != M_force_linear_tmapping)))
+        run_queue();
+    q_kind = kind; q_type = type; q_focus = M_camera_log_focus; q_force = M_force_linear_tmapping;
+    g_host_frame_current = false;
+}
+
+void flatten_polygon(const M_polygon *p, int vertex_base, std::vector<int32_t> &polys, std::vector<int32_t> &aux,
+                     std::vector<int32_t> &pv)
+{
+    int first = (int)(pv.size() / 6);
+    int tex = -1;
+    if (p->m_texture) tex = texture_handle(p->m_texture->m_texture_bytes, p->m_texture->m_log_texture_size);
+    const int32_t hd[4] = {p->m_colour, tex, p->m_no_edges, first};
+    polys.insert(polys.end(), hd, hd + 4);
+    const int32_t ax[4] = {p->m_red, p->m_green, p->m_blue, (p->m_type & 0xff) | (p->m_log_texture_space_size << 8)};
+    aux.insert(aux.end(), ax, ax + 4);
+    for (int k = 0; k <= p->m_no_edges; k++) {
+        const int *r = p->m_vertices + k * M_LNG_POLYGON_VERTEX;
+        const int32_t rec[6] = {r[0] + vertex_base, r[1], r[2], r[3], r[4], r[5]};
+        pv.insert(pv.end(), rec, rec + 6);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ platform
+
+__attribute__((weak)) void HW_error(char *s, ...)
+{
+    va_list lst;
+    va_start(lst, s);
+    vfprintf(stderr, s, lst);
+    va_end(lst);
+    fputc('\n', stderr);
+    exit(1);                                         // the reference shows the message and exits
+}
+
+void HW_init_screen_size(int width, int height) { g_w = width; g_h = height; }
+int HW_screen_x_size(void) { return g_w; }
+int HW_screen_y_size(void) { return g_h; }
+void HW_select_device(int device) { g_device = device; }
+
+void HW_flush(void)
+{
+    need_ctx();
+    run_queue();
+    chk(lt_readback(g_ctx, G_c_buffer, G_z_buffer));
+    g_host_frame_current = true;
+}
+
+// ------------------------------------------------------------------ colour (Colour.cpp:44-102)
+
+void CL_init_colour(void) {}                         // the 256x256 table is evaluated arithmetically
+
+HW_pixel CL_colour(int r, int g, int b)
+{
+    if (r > 255) r = 255;
+    if (g > 255) g = 255;
+    if (b > 255) b = 255;
+    return (r << 16) | (g << 8) | b;
+}
+
+HW_pixel CL_light(HW_pixel colour, int r, int g, int b)
+{
+    int cr = (colour >> 16) & 0xff, cg = (colour >> 8) & 0xff, cb = colour & 0xff;
+    if (r > 255) r = 255;
+    if (g > 255) g = 255;
+    if (b > 255) b = 255;
+    return (((cr * r) / 255) << 16) | (((cg * g) / 255) << 8) | ((cb * b) / 255);
+}
+
+// ------------------------------------------------------------------ graphics
+
+void G_init_graphics(void)
+{
+    if (g_ctx) return;
+    if (lt_ctx_create(g_device, g_w, g_h, &g_ctx) != LT_OK) {
+        char buf[600];
+        snprintf(buf, sizeof buf, "(Graphics) %s", lt_last_error(nullptr));
+        HW_error(buf);
+    }
+    G_c_buffer_size = (long)g_w * g_h;
+    G_c_buffer = (HW_pixel *)malloc(sizeof(HW_pixel) * G_c_buffer_size);
+    G_z_buffer = (int *)malloc(sizeof(int) * G_c_buffer_size);
+    if (!G_c_buffer || !G_z_buffer) HW_error((char *)"(Graphics) Not enough memory.\n");
+    C_init_clipping(0, 0, g_w - 1, g_h - 1);
+}
+
+void G_clear(HW_pixel colour, int red, int green, int blue)
+{
+    need_ctx();
+    run_queue();                                     // earlier draws belong to the frame being replaced
+    chk(lt_clear(g_ctx, CL_light(colour, red, green, blue)));
+    g_host_frame_current = false;
+}
+
+static void queue_screen(int type, int dim, int *edges, int length, HW_pixel colour, int tex)
+{
+    need_ctx();
+    if (length < 2 || length + 1 > G_MAX_POLYGON_VERTICES) HW_error((char *)"(Graphics) polygon outside 2..15 edges.\n");
+    open_queue(Q_SCREEN, type);
+    const int32_t d[4] = {(int32_t)(q_tuples.size() / dim), length, colour, tex};
+    q_desc.insert(q_desc.end(), d, d + 4);
+    q_tuples.insert(q_tuples.end(), edges, edges + (length + 1) * dim);
+    if (length > q_max_edges) q_max_edges = length;
+}
+
+void G_flat_polygon(int *edges, int length, HW_pixel colour, int red, int green, int blue)
+{
+    queue_screen(LT_FLAT, G_LNG_FLAT, edges, length, CL_light(colour, red, green, blue), 0);
+}
+
+void G_shaded_polygon(int *edges, int length, HW_pixel colour)
+{
+    queue_screen(LT_SHADED, G_LNG_SHADED, edges, length, colour, 0);
+}
+
+void G_lin_textured_polygon(int *edges, int length, HW_pixel *texture, int log_texture_size)
+{
+    need_ctx();
+    queue_screen(LT_TEXTURED, G_LNG_TEXTURED, edges, length, 0, texture_handle(texture, log_texture_size));
+}
+
+// ------------------------------------------------------------------ transforms (TransBs.cpp / Trans.cpp)
+
+void T_init_math(void)
+{
+    // Trans.cpp:62-77: scale, then truncate.  (The file the reference's project builds,
+    // TransBs.cpp:70-71, truncates first, which zeroes the tables except cos[0].)
+    for (int i = 0; i < 256; i++) {
+        T_sin_tab[i] = (int)(sin(i / 40.7436642) * (1 << T_P));
+        T_cos_tab[i] = (int)(cos(i / 40.7436642) * (1 << T_P));
+    }
+}
+
+void T_set_self_rotation(unsigned char alp, unsigned char bet, unsigned char gam)
+{
+    const int ca = T_cos_tab[alp], sa = T_sin_tab[alp], cb = T_cos_tab[bet], sb = T_sin_tab[bet];
+    const int cg = T_cos_tab[gam], sg = T_sin_tab[gam];
+    const int sbsg = fx(sb, sg), sbcg = fx(sb, cg);
+    Ts[0] = fx(ca, cg) - fx(sa, sbsg);   Ts[1] = fx(sa, cg) + fx(ca, sbsg);   Ts[2] = fx(cb, sg);     // sx1 sy1 sz1
+    Ts[3] = -fx(sa, cb);                 Ts[4] = fx(ca, cb);                  Ts[5] = -sb;            // sx2 sy2 sz2
+    Ts[6] = -fx(ca, sg) - fx(sa, sbcg);  Ts[7] = fx(ca, sbcg) - fx(sa, sg);   Ts[8] = fx(cb, cg);     // sx3 sy3 sz3
+}
+
+void T_set_world_rotation(unsigned char alp, unsigned char bet, unsigned char gam)
+{
+    const int ca = T_cos_tab[alp], sa = T_sin_tab[alp], cb = T_cos_tab[bet], sb = T_sin_tab[bet];
+    const int cg = T_cos_tab[gam], sg = T_sin_tab[gam];
+    const int sbsa = fx(sb, sa), sbca = fx(sb, ca);
+    Tw[0] = fx(sg, sbsa) + fx(cg, ca);   Tw[1] = fx(cb, sa);   Tw[2] = fx(sg, ca) - fx(cg, sbsa);     // wx1 wy1 wz1
+    Tw[3] = fx(sg, sbca) - fx(cg, sa);   Tw[4] = fx(cb, ca);   Tw[5] = -fx(cg, sbca) - fx(sg, sa);    // wx2 wy2 wz2
+    Tw[6] = -fx(sg, cb);                 Tw[7] = sb;           Tw[8] = fx(cg, cb);                    // wx3 wy3 wz3
+}
+
+void T_cancatinate_self_world(int addx, int addy, int addz)
+{
+    for (int r = 0; r < 3; r++) {
+        const int wx = Tw[3 * r], wy = Tw[3 * r + 1], wz = Tw[3 * r + 2];
+        Tc[4 * r + 0] = wadd(wadd(fx(Ts[0], wx), fx(Ts[3], wy)), fx(Ts[6], wz));
+        Tc[4 * r + 1] = wadd(wadd(fx(Ts[1], wx), fx(Ts[4], wy)), fx(Ts[7], wz));
+        Tc[4 * r + 2] = wadd(wadd(fx(Ts[2], wx), fx(Ts[5], wy)), fx(Ts[8], wz));
+        Tc[4 * r + 3] = wadd(wadd(fx(addx, wx), fx(addy, wy)), fx(addz, wz));
+    }
+}
+
+// Small vertex arrays are transformed on the host with the same arithmetic; the batched
+// GPU transform is what M_render_polygon_object uses (fused into its setup kernel).
+void T_cancatinated_rotation(int *from, int *to, int length)
+{
+    for (int i = 0; i < length; i++, from += 4, to += 4) {
+        const int x = from[0], y = from[1], z = from[2];
+        for (int r = 0; r < 3; r++)
+            to[r] = wadd(wadd(wadd(fx(Tc[4 * r], x), fx(Tc[4 * r + 1], y)), fx(Tc[4 * r + 2], z)), Tc[4 * r + 3]);
+    }
+}
+
+// ------------------------------------------------------------------ clip window (Clipp2D.cpp:35-82)
+
+void C_init_clipping(int minx, int miny, int maxx, int maxy)
+{
+    if (g_ctx && (minx != 0 || miny != 0 || maxx != g_w - 1 || maxy != g_h - 1))
+        HW_error((char *)"(Clipper) only the full-screen clip window is supported by the GPU path.\n");
+    Cb[0] = minx; Cb[1] = miny; Cb[2] = maxx; Cb[3] = maxy;
+}
+
+void C_get_bounds(int *minx, int *miny, int *maxx, int *maxy)
+{
+    *minx = Cb[0]; *miny = Cb[1]; *maxx = Cb[2]; *maxy = Cb[3];
+}
+
+int C_set_bounds(int minx, int miny, int maxx, int maxy)
+{
+    if (minx > Cb[0] || miny > Cb[1] || maxx < Cb[2] || maxy < Cb[3])
+        HW_error((char *)"(Clipper) clip windows smaller than the screen are not supported by the GPU path.\n");
+    return 1;
+}
+
+// ------------------------------------------------------------------ engine (EngBase.cpp / EngPoly.cpp)
+
+void M_init_rendering(int type) { g_rendering_type = type; }
+
+void M_set_camera(unsigned char alp, unsigned char bet, unsigned char gam, int x, int y, int z, int log_focus)
+{
+    T_set_world_rotation((unsigned char)(256 - alp), (unsigned char)(256 - bet), (unsigned char)(256 - gam));
+    M_camera_x = -x; M_camera_y = -y; M_camera_z = -z;
+    M_camera_log_focus = log_focus;
+}
+
+static int lt_type()
+{
+    if (g_rendering_type != M_FLAT && g_rendering_type != M_SHADED && g_rendering_type != M_TEXTURED)
+        HW_error((char *)"(Engine) only M_FLAT, M_SHADED and M_TEXTURED are drawn by the GPU path.\n");
+    return g_rendering_type;
+}
+
+// `vertices` are already transformed (the caller ran T_cancatinated_rotation); the
+// arrays may be temporaries, so the vertices this polygon uses are copied now.
+void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *textures)
+{
+    need_ctx();
+    if (colours || textures) HW_error((char *)"(Engine) per-vertex colour/texture arrays are not supported by the GPU path.\n");
+    const int type = lt_type();
+    open_queue(Q_VIEW, type);
+    const int base = (int)(q_verts.size() / 4);
+    M_polygon tmp = *poly;
+    std::vector<int> recs((size_t)(poly->m_no_edges + 1) * M_LNG_POLYGON_VERTEX);
+    for (int k = 0; k <= poly->m_no_edges; k++) {
+        const int *r = poly->m_vertices + k * M_LNG_POLYGON_VERTEX;
+        const int *v = vertices + (size_t)r[0] * T_LNG_VECTOR;
+        const int32_t vv[4] = {v[0], v[1], v[2], 0};
+        q_verts.insert(q_verts.end(), vv, vv + 4);
+        memcpy(&recs[(size_t)k * 6], r, sizeof(int) * 6);
+        recs[(size_t)k * 6] = k;
+    }
+    tmp.m_vertices = recs.data();
+    flatten_polygon(&tmp, base, q_polys, q_aux, q_pv);
+    if (poly->m_no_edges > q_max_edges) q_max_edges = poly->m_no_edges;
+}
+
+void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam)
+{
+    need_ctx();
+    if (object->m_no_vertices >= M_MAX_OBJECT_VERTICES)
+        HW_error((char *)"(Engine) Can't handle this many vertices in polygons.");      // EngPoly.cpp:507-508
+    if (object->m_order) HW_error((char *)"(Engine) BSP-ordered objects are not supported by the GPU path.\n");
+    const int type = lt_type();
+    run_queue();
+    g_host_frame_current = false;
+    T_set_self_rotation((unsigned char)alp, (unsigned char)bet, (unsigned char)gam);
+    T_cancatinate_self_world(x + M_camera_x, y + M_camera_y, z + M_camera_z);
+    std::vector<int32_t> polys, aux, pv;
+    int me = 0;
+    for (int i = 0; i < object->m_no_polygons; i++) {
+        flatten_polygon(object->m_polygons[i], 0, polys, aux, pv);
+        if (object->m_polygons[i]->m_no_edges > me) me = object->m_polygons[i]->m_no_edges;
+    }
+    chk(lt_submit_object(g_ctx, Tc, object->m_vertices, object->m_no_vertices, polys.data(), aux.data(),
+                         object->m_no_polygons, pv.data(), (int)(pv.size() / 6), type, M_camera_log_focus,
+                         M_force_linear_tmapping, me));
+}

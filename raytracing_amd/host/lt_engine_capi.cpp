@@ -1,0 +1,85 @@
+// extern "C" test shim over the host mirror (lt_engine.h), so that Python tests can drive
+// the reference-named C++ API: it builds the M_polygon / M_polygon_object structures from
+// the flat scene arrays and calls the mirror exactly as a reference-style program would.
+#include "lt_engine.h"
+#include <stddef.h>
+#include <vector>
+
+extern "C" {
+
+void lte_init(int w, int h)
+{
+    HW_init_screen_size(w, h);
+    T_init_math();
+    CL_init_colour();
+    G_init_graphics();
+}
+
+int *lte_cbuf(void) { return (int *)G_c_buffer; }
+int *lte_zbuf(void) { return G_z_buffer; }
+void lte_clear(int colour, int r, int g, int b) { G_clear(colour, r, g, b); }
+void lte_flush(void) { HW_flush(); }
+int lte_cl_light(int c, int r, int g, int b) { return CL_light(c, r, g, b); }
+
+static void fill(M_polygon *p, M_texture *texs, const int *polys, const int *aux, int *pv, int i)
+{
+    p->m_type = aux ? (aux[i * 4 + 3] & 0xff) : M_PLANNAR;
+    p->m_colour = polys[i * 4];
+    p->m_red = aux ? aux[i * 4] : 0; p->m_green = aux ? aux[i * 4 + 1] : 0; p->m_blue = aux ? aux[i * 4 + 2] : 0;
+    p->m_log_texture_space_size = aux ? (aux[i * 4 + 3] >> 8) : 0;
+    p->m_texture = polys[i * 4 + 1] >= 0 ? &texs[polys[i * 4 + 1]] : nullptr;
+    p->m_no_edges = polys[i * 4 + 2];
+    p->m_vertices = pv + (size_t)polys[i * 4 + 3] * 6;
+    p->m_normals = nullptr;
+}
+
+static M_texture g_texs[64];
+void lte_set_texture(int handle, int *texels, int log_size)
+{
+    g_texs[handle].m_texture_bytes = texels;
+    g_texs[handle].m_log_texture_size = log_size;
+}
+
+// M_set_camera + M_render_polygon_object on one object
+void lte_render_object(int *verts, int nv, const int *polys, const int *aux, int *pv, int np, int type,
+                       int cam_alp, int cam_bet, int cam_gam, int cam_x, int cam_y, int cam_z, int log_focus,
+                       int x, int y, int z, int alp, int bet, int gam)
+{
+    std::vector<M_polygon> store(np);
+    std::vector<M_polygon *> ptrs(np);
+    for (int i = 0; i < np; i++) { fill(&store[i], g_texs, polys, aux, pv, i); ptrs[i] = &store[i]; }
+    M_polygon_object obj;
+    obj.m_type = M_POLYGON_OBJECT; obj.m_order = nullptr;
+    obj.m_no_polygons = np; obj.m_polygons = ptrs.data();
+    obj.m_no_vertices = nv; obj.m_vertices = verts;
+    obj.m_no_normals = 0; obj.m_normals = nullptr;
+    M_init_rendering(type);
+    M_set_camera((unsigned char)cam_alp, (unsigned char)cam_bet, (unsigned char)cam_gam, cam_x, cam_y, cam_z, log_focus);
+    M_render_polygon_object(&obj, x, y, z, alp, bet, gam);
+}
+
+// the transform, then one M_render_polygon call per polygon (as EngPoly.cpp:512-523 does)
+void lte_render_polys_one_by_one(int *verts, int nv, const int *polys, const int *aux, int *pv, int np, int type,
+                                 int log_focus, int x, int y, int z, int alp, int bet, int gam)
+{
+    std::vector<int> tmp((size_t)nv * 4);
+    M_init_rendering(type);
+    M_set_camera(0, 0, 0, 0, 0, 0, log_focus);
+    T_set_self_rotation((unsigned char)alp, (unsigned char)bet, (unsigned char)gam);
+    T_cancatinate_self_world(x + M_camera_x, y + M_camera_y, z + M_camera_z);
+    T_cancatinated_rotation(verts, tmp.data(), nv);
+    for (int i = 0; i < np; i++) {
+        M_polygon p;
+        fill(&p, g_texs, polys, aux, pv, i);
+        M_render_polygon(&p, tmp.data(), nullptr, nullptr);
+    }
+}
+
+void lte_g_polygon(int kind, int *tuples, int length, int colour, int r, int g, int b, int tex)
+{
+    if (kind == M_FLAT) G_flat_polygon(tuples, length, colour, r, g, b);
+    else if (kind == M_SHADED) G_shaded_polygon(tuples, length, colour);
+    else G_lin_textured_polygon(tuples, length, g_texs[tex].m_texture_bytes, g_texs[tex].m_log_texture_size);
+}
+
+}  // extern "C"

@@ -1,0 +1,82 @@
+"""The C++ host mirror of the reference's API (raytracing_amd/host/lt_engine.h) driving
+the HIP library: M_render_polygon_object, M_render_polygon and G_*_polygon called as a
+reference-style program would, checked against the CPU checker."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+W, H = 200, 150
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch  # noqa: F401  (HIP runtime first, see raytracing_amd/_lib.py)
+    from raytracing_amd import _lib
+    _lib.lib()
+    so = os.path.join(os.path.dirname(_lib.SO_PATH), "liblt_engine.so")
+    L = C.CDLL(so)
+    L.lte_cbuf.restype = C.POINTER(C.c_int32)
+    L.lte_zbuf.restype = C.POINTER(C.c_int32)
+    L.lte_init(W, H)
+    return L
+
+
+def _frame(L):
+    L.lte_flush()
+    c = np.ctypeslib.as_array(L.lte_cbuf(), shape=(H, W)).copy()
+    z = np.ctypeslib.as_array(L.lte_zbuf(), shape=(H, W)).copy()
+    return c, z
+
+
+@pytest.mark.parametrize("rt", [S.M_SHADED, S.M_FLAT, S.M_TEXTURED])
+def test_render_polygon_object(eng, rt):
+    import oracle.port as P
+    sc = S.gen_fuzz_polys(120, W, H, 7, 4000 + rt, render_type=rt, textured=rt == S.M_TEXTURED, equal_lights=False)
+    assert sc.verts.shape[0] < 1024
+    cam = (5, 250, 3, 10, -5, -40)
+    obj = (7, 9, 250, 3, 4, 60)
+    tex = None
+    orc = P.Oracle(W, H)
+    if sc.textures:
+        tex = np.ascontiguousarray(sc.textures[0][0], dtype=np.int32)
+        eng.lte_set_texture(0, _p(tex), sc.textures[0][1])
+        orc.set_texture(0, tex, sc.textures[0][1])
+    orc.clear(0x203040, 250, 240, 230)
+    m = P.make_matrix(cam, obj, 0)
+    orc.render_polys(P.transform(m, sc.verts), sc.polys, sc.polyaux, sc.polyverts, rt, sc.log_focus)
+    eng.lte_clear(0x203040, 250, 240, 230)
+    v, po, pa, pv = sc.verts.copy(), sc.polys.copy(), sc.polyaux.copy(), sc.polyverts.copy()
+    eng.lte_render_object(_p(v), v.shape[0], _p(po), _p(pa), _p(pv), po.shape[0], rt, *cam, sc.log_focus, *obj[3:], *obj[:3])
+    c, z = _frame(eng)
+    assert np.array_equal(z, orc.zbuf()) and np.array_equal(c, orc.cbuf())
+
+
+def test_render_polygon_one_by_one_and_screen_polys(eng):
+    import oracle.port as P
+    sc = S.gen_c2(1500, W, H, 7, radius=14, seed=21)
+    orc = P.Oracle(W, H)
+    orc.clear(0, 0, 0, 0)
+    obj = (3, 5, 7, 2, -3, 20)
+    m = P.make_matrix((0, 0, 0, 0, 0, 0), obj, 0)
+    orc.render_polys(P.transform(m, sc.verts), sc.polys, None, sc.polyverts, S.M_SHADED, sc.log_focus)
+    polys = S.gen_screen_polys(60, W, H, seed=5, dim=6)
+    for (e, t, col) in polys:
+        orc.g_polygon(4, t, colour=col)
+    eng.lte_clear(0, 0, 0, 0)
+    v, po, pv = sc.verts.copy(), sc.polys.copy(), sc.polyverts.copy()
+    eng.lte_render_polys_one_by_one(_p(v), v.shape[0], _p(po), None, _p(pv), po.shape[0], S.M_SHADED, sc.log_focus,
+                                    *obj[3:], *obj[:3])
+    for (e, t, col) in polys:
+        tt = np.ascontiguousarray(t, dtype=np.int32)
+        eng.lte_g_polygon(4, _p(tt), e, col, 0, 0, 0, 0)
+    c, z = _frame(eng)
+    assert np.array_equal(z, orc.zbuf()) and np.array_equal(c, orc.cbuf())
