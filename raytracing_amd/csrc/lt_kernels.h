@@ -37,6 +37,14 @@ constexpr int PRP_INTS = 12;
 // word would queue behind each other (one chip-wide atomic per ~12 ns on one address);
 // the host sums the slots.
 constexpr int STATUS_SLOTS = 256;
+constexpr int QUEUES = 64;                 // sub-queues between the fast and the general setup kernel
+constexpr int QUEUE_COUNT_STRIDE = 32;     // words between their counters (one 128-byte line each)
+constexpr int SETUP_FAST_THREADS = 256;
+inline unsigned setup_queue_cap(int np)
+{
+    unsigned blocks = (unsigned)((np + SETUP_FAST_THREADS - 1) / SETUP_FAST_THREADS);
+    return ((blocks + QUEUES - 1) / QUEUES) * SETUP_FAST_THREADS;
+}
 struct Status {
     unsigned long long fragments;
     unsigned long long polys_drawn;
@@ -61,6 +69,9 @@ struct SetupArgs {
     int emax;                // edge slots per polygon
     PrimHdr *hdr;
     int *edges;
+    unsigned *queue;         // polygons left to the general kernel by the fast one (null: general kernel takes all)
+    unsigned *queue_count;   // QUEUES counters, QUEUE_COUNT_STRIDE words apart
+    unsigned queue_cap;      // entries per sub-queue
     int *order_flag;         // device word raised when a textured polygon's vertex lights differ
     int detect_order;
     int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null

@@ -49,15 +49,16 @@ __device__ __forceinline__ int tdivr(int n, double r)
 }
 
 // floor(n / d) for 0 <= n < 2^30 and 1 <= d <= 2^15 with a quotient below 2^15 (the
-// point-index divisions of the edge walk): single-precision estimate, then one exact
-// correction step from the remainder.
-__device__ __forceinline__ int udiv_small(int n, int d)
+// point-index divisions of the edge walk), given rd ~ 1/d in single precision: the
+// estimate is within one of the quotient, and one exact correction step from the
+// remainder settles it.  The products fit 24-bit multiplies (full rate on the VALU).
+__device__ __forceinline__ int udiv_r(int n, int d, float rd)
 {
-    int q = (int)((float)n * __builtin_amdgcn_rcpf((float)d));
-    int r = n - q * d;
-    if (r < 0) { q--; r += d; }
-    if (r >= d) q++;
-    return q;
+    int q = (int)((float)n * rd);
+    int r = n - __mul24(q, d);
+    q = r < 0 ? q - 1 : q;
+    r = r < 0 ? r + d : r;
+    return r >= d ? q + 1 : q;
 }
 
 // CL_light (Colour.cpp:93-102): per channel (c*min(l,255))/255, evaluated
@@ -263,6 +264,168 @@ __device__ bool tmapping_vectors(int type, const Tup<8> &p1, const Tup<8> &p2, c
 
 constexpr int KIND_FLAT = 2, KIND_SHADED = 4, KIND_TEX_LIN = 8, KIND_TEX_PRP = 9;
 
+// Edge record of one scanned edge v1 -> v2 (after the y clip): GI_scan's set-up,
+// GraphicsPoly.cpp:147-176.  record = {x1|y1<<16, x2|y2<<16, Zstart, Zinc, other starts..,
+// other incs..} in 16-byte pieces; edge `slot` of every polygon lies in plane `slot`.
+template <int DIM>
+__device__ __forceinline__ void store_edge_record(const SetupArgs &a, int poly, int slot, const Tup<DIM> &v1,
+                                                  const Tup<DIM> &v2)
+{
+    constexpr int NA = DIM - 2;
+    constexpr int ESZ = edge_ints(NA);
+    const int x1 = v1.v[0], y1 = v1.v[1], x2 = v2.v[0], y2 = v2.v[1];
+    int dx = x2 - x1, dy = y2 - y1;
+    dx = dx < 0 ? -dx : dx;
+    dy = dy < 0 ? -dy : dy;
+    const int L = dx > dy ? dx : dy;
+    int rec[ESZ];
+#pragma unroll
+    for (int q = 0; q < ESZ; q++) rec[q] = 0;
+    rec[0] = x1 | (y1 << 16);
+    rec[1] = x2 | (y2 << 16);
+    const double rL = drcp(L > 0 ? L : 1);
+    rec[2] = wshl(v1.v[2], 16);
+    rec[3] = L > 0 ? tdivr(wshl(wsub(v2.v[2], v1.v[2]), 16), rL) : 0;
+#pragma unroll
+    for (int q = 1; q < NA; q++) {
+        rec[3 + q] = v1.v[2 + q];
+        rec[3 + (NA - 1) + q] = L > 0 ? tdivr(wsub(v2.v[2 + q], v1.v[2 + q]), rL) : 0;
+    }
+    int4 *r = (int4 *)(a.edges + ((size_t)slot * a.np + poly) * ESZ);
+#pragma unroll
+    for (int q = 0; q < ESZ / 4; q++) r[q] = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+}
+
+// Triangles that need no clipping at all take this kernel: volume test passed with every
+// z >= 10, and all four projected tuples strictly inside the screen, so that the z, x and y
+// clippers would pass every edge through unchanged (Clipp3D.cpp:91, Clipp2D.cpp:115-136,
+// 188-209).  The screen clipper then emits the second tuple of each edge, i.e. the
+// polygon rotated by one (Clipp2D.cpp:265-272): scanned edges are p1->p2, p2->p3, p3->p1
+// with p3 the stored closing tuple.  Everything else (other edge counts, near-plane or
+// screen-border contact, perspective-mapped textures) is appended to a queue for the
+// general kernel, which then runs only on those polygons with all its lanes busy.
+template <int DIM>
+__global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
+{
+    constexpr int NA = DIM - 2;
+    const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool inrange = poly < a.np;
+    bool slow = false, drawn = false, vary = false;
+    int4 hdr = make_int4(0, 0, 0, 0);
+    if (inrange) {
+        const int4 pd = ((const int4 *)a.polys)[poly];
+        const int colour = pd.x, tex = pd.y, e = pd.z, first = pd.w;
+        int kind = a.render_type;
+        if (kind == KIND_TEX_LIN && tex < 0) kind = KIND_SHADED;
+        if (e != 3 || e > a.max_edges || first < 0 || (long long)first + 4 > (long long)a.npv ||
+            (kind == KIND_TEX_LIN && tex >= 64))
+            slow = true;
+        Tup<DIM> t[4];
+        if (!slow) {
+            int2 ra[4], rb[4], rc[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int2 *rec = (const int2 *)(a.polyverts + (size_t)(first + i) * 6);
+                ra[i] = rec[0];
+                rb[i] = DIM >= 6 ? rec[1] : make_int2(0, 0);
+                rc[i] = DIM == 8 ? rec[2] : make_int2(0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if ((unsigned)ra[i].x >= (unsigned)a.nv) slow = true;
+            if (!slow) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int4 p = load_vertex(a, ra[i].x);
+                    t[i].v[0] = p.x; t[i].v[1] = p.y; t[i].v[2] = p.z;
+                    if (DIM >= 6) { t[i].v[3] = wshl(ra[i].y, 16); t[i].v[4] = wshl(rb[i].x, 16); t[i].v[5] = wshl(rb[i].y, 16); }
+                    if (DIM == 8) {
+                        const bool tx = kind == KIND_TEX_LIN;
+                        t[i].v[DIM - 2] = tx ? wshl(rc[i].x, 16) : 0;
+                        t[i].v[DIM - 1] = tx ? wshl(rc[i].y, 16) : 0;
+                    }
+                }
+            }
+        }
+        bool go = !slow;
+        if (go) {
+            // C_volume_clipping, Clipp3D.cpp:46-58
+            int mn[3], mx[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mn[j] = min(min(t[0].v[j], t[1].v[j]), min(t[2].v[j], t[3].v[j]));
+                mx[j] = max(max(t[0].v[j], t[1].v[j]), max(t[2].v[j], t[3].v[j]));
+            }
+            if ((mx[2] < mn[0]) || (mx[2] < mn[1]) || (mx[2] < -mx[0]) || (mx[2] < -mx[1]) || (mx[2] <= 10)) go = false;
+            else if (mn[2] < 10) { slow = true; go = false; }
+        }
+        if (go && DIM == 8 && kind == KIND_TEX_LIN && (a.force_linear || t[0].v[2] < 1024)) { slow = true; go = false; }
+        if (go) {
+            if (DIM == 8)
+                vary = t[1].v[3] != t[0].v[3] || t[1].v[4] != t[0].v[4] || t[1].v[5] != t[0].v[5] ||
+                       t[2].v[3] != t[0].v[3] || t[2].v[4] != t[0].v[4] || t[2].v[5] != t[0].v[5] ||
+                       t[3].v[3] != t[0].v[3] || t[3].v[4] != t[0].v[4] || t[3].v[5] != t[0].v[5];
+            // T_perspective, TransBs.cpp:425-432
+            const int xc = a.W / 2, yc = a.H / 2;
+            bool inside = true;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int z = t[i].v[2];
+                const double rz = drcp(z);
+                t[i].v[0] = wadd(persp_div(t[i].v[0], a.log_focus, z, rz), xc);
+                t[i].v[1] = wadd(persp_div(t[i].v[1], a.log_focus, z, rz), yc);
+                t[i].v[2] = tdivr(-0x7ffff, rz);
+                inside = inside && t[i].v[0] > 0 && t[i].v[0] < a.W - 1 && t[i].v[1] > 0 && t[i].v[1] < a.H - 1;
+            }
+            if (!inside) { slow = true; go = false; }
+        }
+        if (go) {
+            // T_normal_z_negative, TransLn.cpp:218-223
+            const long long c = (long long)wsub(t[1].v[0], t[0].v[0]) * (long long)wsub(t[2].v[1], t[0].v[1]) -
+                                (long long)wsub(t[1].v[1], t[0].v[1]) * (long long)wsub(t[2].v[0], t[0].v[0]);
+            if (!(c < 0)) go = false;
+        }
+        if (go) {
+            drawn = true;
+            const int miny = min(t[1].v[1], min(t[2].v[1], t[3].v[1])), maxy = max(t[1].v[1], max(t[2].v[1], t[3].v[1]));
+            const int minx = min(t[1].v[0], min(t[2].v[0], t[3].v[0])), maxx = max(t[1].v[0], max(t[2].v[0], t[3].v[0]));
+            if (miny < maxy) {
+                store_edge_record<DIM>(a, poly, 0, t[1], t[2]);
+                store_edge_record<DIM>(a, poly, 1, t[2], t[3]);
+                store_edge_record<DIM>(a, poly, 2, t[3], t[1]);
+                int col = colour;
+                if (kind == KIND_FLAT) {
+                    const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
+                    col = cl_light(colour, ax.x, ax.y, ax.z);
+                }
+                hdr = make_int4(miny | (maxy << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
+            }
+        }
+        if (!slow) ((int4 *)a.hdr)[poly] = hdr;
+    }
+    // queue the rest for the general kernel: one atomic per wave, spread over QUEUES
+    // sub-queues by workgroup index (thousands of waves adding to one word would queue
+    // behind each other); sub-queue q holds at most `queue_cap` entries by construction
+    const unsigned long long sm = __ballot(slow);
+    if (sm) {
+        const int lane = threadIdx.x & 63;
+        const int leader = __ffsll((long long)sm) - 1;
+        const int q = blockIdx.x % QUEUES;
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(a.queue_count + q * QUEUE_COUNT_STRIDE, (unsigned)__popcll(sm));
+        base = __shfl(base, leader);
+        if (slow) a.queue[(size_t)q * a.queue_cap + base + __popcll(sm & ((1ull << lane) - 1ull))] = (unsigned)poly;
+    }
+    Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
+    const unsigned long long dm = __ballot(drawn);
+    if (dm && (threadIdx.x & 63) == (__ffsll((long long)dm) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(dm));
+    if (DIM == 8 && a.detect_order) {
+        const unsigned long long om = __ballot(drawn && vary);
+        if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = 1;
+    }
+}
+
+
 // One polygon per lane.  The stages of M_render_polygon (EngBase.cpp:379-552) and of
 // G_*_polygon up to the edge scan (GraphicsPoly.cpp:318-323) are chained as a stream:
 // a stage hands each tuple it produces to the next stage at once, so a lane holds a
@@ -286,7 +449,11 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     constexpr int NA = DIM - 2;
     constexpr int ESZ = edge_ints(NA);
     int poly = blockIdx.x * blockDim.x + threadIdx.x;
-    if (poly >= a.np) return;
+    if (a.queue) {
+        // second stage: only the polygons that the fast kernel passed on (sub-queue blockIdx.y)
+        if ((unsigned)poly >= a.queue_count[blockIdx.y * QUEUE_COUNT_STRIDE]) return;
+        poly = (int)a.queue[(size_t)blockIdx.y * a.queue_cap + poly];
+    } else if (poly >= a.np) return;
 
     PrimHdr hdr;
     hdr.yy = 0; hdr.xx = 0; hdr.colour = 0; hdr.meta = 0;
@@ -513,34 +680,9 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                     Tup<DIM> v1, v2;
                     bool moved;
                     if (clip_line<DIM, 1, true>(sprev, s, 0, hy, v1, v2, moved, bad)) {
-                        int x1 = v1.v[0], y1 = v1.v[1], x2 = v2.v[0], y2 = v2.v[1];
-                        miny = min(miny, min(y1, y2));
-                        maxy = max(maxy, max(y1, y2));
-                        int dx = x2 - x1, dy = y2 - y1;
-                        dx = dx < 0 ? -dx : dx;
-                        dy = dy < 0 ? -dy : dy;
-                        int L = dx > dy ? dx : dy;
-                        if (ne < a.emax) {
-                            // record = {x1|y1<<16, x2|y2<<16, Z start, Z inc, other starts.., other incs..},
-                            // 16-byte pieces; edge k of every polygon lies in plane k of the pool
-                            int rec[ESZ];
-#pragma unroll
-                            for (int q = 0; q < ESZ; q++) rec[q] = 0;
-                            rec[0] = x1 | (y1 << 16);
-                            rec[1] = x2 | (y2 << 16);
-                            const double rL = drcp(L > 0 ? L : 1);
-                            rec[2] = wshl(v1.v[2], 16);
-                            rec[3] = L > 0 ? tdivr(wshl(wsub(v2.v[2], v1.v[2]), 16), rL) : 0;
-#pragma unroll
-                            for (int q = 1; q < NA; q++) {
-                                rec[3 + q] = v1.v[2 + q];
-                                rec[3 + (NA - 1) + q] = L > 0 ? tdivr(wsub(v2.v[2 + q], v1.v[2 + q]), rL) : 0;
-                            }
-                            int4 *r = (int4 *)(a.edges + ((size_t)ne * a.np + poly) * ESZ);
-#pragma unroll
-                            for (int q = 0; q < ESZ / 4; q++)
-                                r[q] = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
-                        }
+                        miny = min(miny, min(v1.v[1], v2.v[1]));
+                        maxy = max(maxy, max(v1.v[1], v2.v[1]));
+                        if (ne < a.emax) store_edge_record<DIM>(a, poly, ne, v1, v2);
                         ne++;
                     }
                 }
@@ -618,7 +760,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     }
 
     // counters: one atomic per wave, spread over the status slots
-    Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
+    Status *st = a.status + ((blockIdx.x + blockIdx.y) % STATUS_SLOTS);
     unsigned long long m;
     m = __ballot(reached_fill);
     if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(m));
@@ -795,37 +937,55 @@ __global__ void __launch_bounds__(1024) scan_kernel(const unsigned *__restrict__
 // leftmost and rightmost point on that edge; it returns false if the edge misses the row.
 __device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &xa, int &ib, int &xb)
 {
-    int x1 = xy1 & 0xffff, y1 = (xy1 >> 16) & 0xffff, x2 = xy2 & 0xffff, y2 = (xy2 >> 16) & 0xffff;
-    int dx = x2 - x1, dy = y2 - y1;
-    int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-    int j = dy < 0 ? y1 - y : y - y1;
-    if ((unsigned)j > (unsigned)ady) return false;
-    if (adx > ady) {
-        int L = adx, s = ady, ilo, ihi;
-        if (s == 0) { ilo = 0; ihi = L; }
-        else {
-            ilo = j == 0 ? 0 : udiv_small(2 * L * j - L + 2 * s - 1, 2 * s);
-            ihi = j == s ? L : udiv_small(2 * L * (j + 1) - L + 2 * s - 1, 2 * s) - 1;
-        }
-        if (dx >= 0) { ia = ilo; ib = ihi; xa = x1 + ilo; xb = x1 + ihi; }
-        else         { ia = ihi; ib = ilo; xa = x1 - ihi; xb = x1 - ilo; }
-    } else {
-        int L = ady, s = adx;
-        int h = L == 0 ? 0 : udiv_small(2 * s * j + L, 2 * L);
-        ia = ib = j;
-        xa = xb = dx < 0 ? x1 - h : x1 + h;
-    }
-    return true;
+    // Branch-free: both the y-major and the x-major forms divide by 2*|dy| (2L for a
+    // y-major edge, 2s for an x-major one), so one reciprocal serves the three quotients
+    // and selects pick the form that applies.
+    const int x1 = xy1 & 0xffff, y1 = (xy1 >> 16) & 0xffff, x2 = xy2 & 0xffff, y2 = (xy2 >> 16) & 0xffff;
+    const int dx = x2 - x1, dy = y2 - y1;
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    const int j = dy < 0 ? y1 - y : y - y1;
+    const bool hit = (unsigned)j <= (unsigned)ady;
+    const bool xmaj = adx > ady;
+    const int d2 = ady > 0 ? 2 * ady : 1;                       // a horizontal edge or a point uses no quotient
+    const float rd = __builtin_amdgcn_rcpf((float)d2);
+    const int a2j = __mul24(2 * adx, j);
+    const int nB = a2j - adx + 2 * ady - 1;
+    const int h = udiv_r(a2j + ady, d2, rd);                   // y-major: diagonal steps before point j
+    const int qB = udiv_r(nB, d2, rd);                          // x-major: first point of row j (j >= 1)
+    const int qC = udiv_r(nB + 2 * adx, d2, rd);                // x-major: first point of row j+1
+    const int ilo = j == 0 ? 0 : qB;
+    const int ihi = j == ady ? adx : qC - 1;
+    const int lo = xmaj ? ilo : j, hi = xmaj ? ihi : j;         // point indices of the row's two end points
+    const int olo = xmaj ? ilo : h, ohi = xmaj ? ihi : h;       // their x distances from x1
+    const bool fwd = dx >= 0;
+    ia = fwd ? lo : hi;
+    ib = fwd ? hi : lo;
+    xa = fwd ? x1 + olo : x1 - ohi;
+    xb = fwd ? x1 + ohi : x1 - olo;
+    return hit;
 }
 
 // Row ends with all NA interpolated values (used by the colour pass).
 template <int NA>
 __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, int poly, int ne, int y, int &beg,
-                                         int &end, int (&S)[NA], int (&E)[NA])
+                                         int &end, int (&S)[NA], int (&E)[NA], const int2 *pre = nullptr)
 {
     constexpr int ESZ = edge_ints(NA);
     int bx = INT_MAX, ex = INT_MIN, be = 0, bi = 0, ee = 0, ei = 0;
-    for (int e = 0; e < ne; e++) {
+    // `pre`: coordinates of edges 0..2 already fetched by the caller
+    int first = 0;
+    if (pre) {
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            int ia, xa, ib, xb;
+            if (e < ne && edge_row(pre[e].x, pre[e].y, y, ia, xa, ib, xb)) {
+                if (xa < bx) { bx = xa; be = e; bi = ia; }
+                if (ex < xb) { ex = xb; ee = e; ei = ib; }
+            }
+        }
+        first = 3;
+    }
+    for (int e = first; e < ne; e++) {
         const int2 xy = *(const int2 *)(edges + ((size_t)e * np + poly) * ESZ);
         int ia, xa, ib, xb;
         if (!edge_row(xy.x, xy.y, y, ia, xa, ib, xb)) continue;
@@ -860,16 +1020,18 @@ struct Edge4 { int xy1, xy2, z0, zi; };
 
 __device__ __forceinline__ bool depth_row3(const Edge4 (&ed)[3], int ne, int y, int &beg, int &end, int &zs, int &zi)
 {
-    int bx = INT_MAX, ex = INT_MIN, sz = 0, ez = 0;
+    int bx = INT_MAX, ex = INT_MIN;
+    int bz0 = 0, bzi = 0, bi = 0, ez0 = 0, ezi = 0, ei = 0;       // the owning edges' depth walk and point index
 #pragma unroll
     for (int e = 0; e < 3; e++) {
         int ia, xa, ib, xb;
-        if (e < ne && edge_row(ed[e].xy1, ed[e].xy2, y, ia, xa, ib, xb)) {
-            if (xa < bx) { bx = xa; sz = wadd(ed[e].z0, wmul(ia, ed[e].zi)); }
-            if (ex < xb) { ex = xb; ez = wadd(ed[e].z0, wmul(ib, ed[e].zi)); }
-        }
+        const bool hit = edge_row(ed[e].xy1, ed[e].xy2, y, ia, xa, ib, xb) && e < ne;
+        const bool tb = hit && xa < bx, te = hit && ex < xb;
+        bx = tb ? xa : bx; bz0 = tb ? ed[e].z0 : bz0; bzi = tb ? ed[e].zi : bzi; bi = tb ? ia : bi;
+        ex = te ? xb : ex; ez0 = te ? ed[e].z0 : ez0; ezi = te ? ed[e].zi : ezi; ei = te ? ib : ei;
     }
     if (bx == INT_MAX) return false;
+    const int sz = wadd(bz0, wmul(bi, bzi)), ez = wadd(ez0, wmul(ei, ezi));
     int span = ex - bx;
     if (span == 0) span = 1;
     beg = bx; end = ex; zs = sz;
@@ -1066,6 +1228,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
 {
     constexpr int ESZ = edge_ints(NA);
     __shared__ unsigned long long keys[TH * TW];
+    __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 lanes x {edge0, edge1, edge2, {poly, ne, r0, offset}}
 
     const int t = threadIdx.x, lane = t & 63;
     const int tile = blockIdx.x;
@@ -1088,50 +1251,112 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
 
     unsigned long long frags = 0;
 
-    // ---- depth pass
+    // ---- depth pass.  Loads are software-pipelined: while a round's rows are drawn, the
+    // header and the depth pieces of the three first edge records of the next round's
+    // polygons are in flight, and so is the list entry of the round after that.  The edge
+    // pieces do not wait for the header: planes 0..2 of the pool exist for every polygon.
     const unsigned rounds = (lcnt + RASTER_THREADS - 1) / RASTER_THREADS;
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    int poly_c = t < lcnt ? (int)a.tile_list[lbeg + t] : -1;
+    int poly_n = (unsigned)(RASTER_THREADS + t) < lcnt ? (int)a.tile_list[lbeg + RASTER_THREADS + t] : -1;
+    int4 h_c = zero4, e0_c = zero4, e1_c = zero4, e2_c = zero4;
+    if (poly_c >= 0) {
+        h_c = ((const int4 *)a.hdr)[poly_c];
+        e0_c = *(const int4 *)(a.edges + ((size_t)0 * a.np + poly_c) * ESZ);
+        e1_c = *(const int4 *)(a.edges + ((size_t)1 * a.np + poly_c) * ESZ);
+        e2_c = *(const int4 *)(a.edges + ((size_t)2 * a.np + poly_c) * ESZ);
+    }
     for (unsigned rd = 0; rd < rounds; rd++) {
-        const unsigned li = rd * RASTER_THREADS + t;
-        int poly = -1, ne = 0, r0 = 0, r1 = 0, cx0 = 0, cx1 = -1;
-        Edge4 ed[3];
-#pragma unroll
-        for (int e = 0; e < 3; e++) { ed[e].xy1 = 0; ed[e].xy2 = 0; ed[e].z0 = 0; ed[e].zi = 0; }
-        if (li < lcnt) {
-            poly = (int)a.tile_list[lbeg + li];
-            const int4 h = ((const int4 *)a.hdr)[poly];
-            ne = h.w & 0xff;
-            r0 = max(h.x & 0xffff, ty0);
-            r1 = min((h.x >> 16) & 0xffff, ty0 + TH);
-            cx0 = max(h.y & 0xffff, tx0);
-            cx1 = min((h.y >> 16) & 0xffff, tx0 + TW - 1);
-#pragma unroll
-            for (int e = 0; e < 3; e++)
-                if (e < ne) {
-                    const int4 r = *(const int4 *)(a.edges + ((size_t)e * a.np + poly) * ESZ);
-                    ed[e].xy1 = r.x; ed[e].xy2 = r.y; ed[e].z0 = r.z; ed[e].zi = r.w;
-                }
+        int4 h_n = zero4, e0_n = zero4, e1_n = zero4, e2_n = zero4;
+        if (poly_n >= 0) {
+            h_n = ((const int4 *)a.hdr)[poly_n];
+            e0_n = *(const int4 *)(a.edges + ((size_t)0 * a.np + poly_n) * ESZ);
+            e1_n = *(const int4 *)(a.edges + ((size_t)1 * a.np + poly_n) * ESZ);
+            e2_n = *(const int4 *)(a.edges + ((size_t)2 * a.np + poly_n) * ESZ);
         }
+        const unsigned li2 = (rd + 2) * RASTER_THREADS + t;
+        const int poly_nn = li2 < lcnt ? (int)a.tile_list[lbeg + li2] : -1;
+
+        const int poly = poly_c;
+        int ne = 0, r0 = 0, r1 = 0, cx0 = 0, cx1 = -1;
+        Edge4 ed[3];
+        ed[0].xy1 = e0_c.x; ed[0].xy2 = e0_c.y; ed[0].z0 = e0_c.z; ed[0].zi = e0_c.w;
+        ed[1].xy1 = e1_c.x; ed[1].xy2 = e1_c.y; ed[1].z0 = e1_c.z; ed[1].zi = e1_c.w;
+        ed[2].xy1 = e2_c.x; ed[2].xy2 = e2_c.y; ed[2].z0 = e2_c.z; ed[2].zi = e2_c.w;
+        if (poly >= 0) {
+            ne = h_c.w & 0xff;
+            r0 = max(h_c.x & 0xffff, ty0);
+            r1 = min((h_c.x >> 16) & 0xffff, ty0 + TH);
+            cx0 = max(h_c.y & 0xffff, tx0);
+            cx1 = min((h_c.y >> 16) & 0xffff, tx0 + TW - 1);
+        }
+        poly_c = poly_n; poly_n = poly_nn;
+        h_c = h_n; e0_c = e0_n; e1_c = e1_n; e2_c = e2_n;
         const bool live = poly >= 0 && r0 < r1 && cx0 <= cx1;
         const bool big = live && (r1 - r0) * (cx1 - cx0 + 1) >= BIG_AREA;
 
-        // small polygons: one lane each
-        if (live && !big) {
-            const unsigned id = (unsigned)poly + 1u;
-            for (int y = r0; y < r1; y++) {
-                int beg, end, zs, zi;
-                bool ok = ne <= 3 ? depth_row3(ed, ne, y, beg, end, zs, zi)
-                                  : depth_row_mem(a.edges, ESZ, a.np, poly, ne, y, beg, end, zs, zi);
-                if (!ok) continue;
-                int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
-                if (xa > xb) continue;
-                frags += (unsigned long long)(xb - xa + 1);
-                unsigned long long *krow = keys + (y - ty0) * TW - tx0;
-                int z = wadd(zs, wmul(xa - beg, zi));
-                for (int x = xa; x <= xb; x++) {
-                    atomicMin(&krow[x], depth_key(z >> 16, id));
-                    z = wadd(z, zi);
+        // small polygons: their rows inside the tile are numbered through a wave-wide
+        // prefix sum and dealt one row per lane, 64 rows per step, so lanes stay busy
+        // whatever the mix of polygon heights.  A lane publishes its polygon's depth-pass
+        // data in the wave's own LDS staging rows; the lane that draws a row reads the
+        // owner's data back (ordering inside one wave: LDS operations complete in issue order).
+        {
+            const int cnt = (live && !big) ? r1 - r0 : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const int total = __shfl(incl, 63);
+            int4 *st = stage + (size_t)(t & ~63) * 4;       // this wave's 64 x 4 pieces
+            st[lane * 4 + 0] = make_int4(ed[0].xy1, ed[0].xy2, ed[0].z0, ed[0].zi);
+            st[lane * 4 + 1] = make_int4(ed[1].xy1, ed[1].xy2, ed[1].z0, ed[1].zi);
+            st[lane * 4 + 2] = make_int4(ed[2].xy1, ed[2].xy2, ed[2].z0, ed[2].zi);
+            st[lane * 4 + 3] = make_int4(poly, ne, r0, incl - cnt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int rb = 0; rb < total; rb += 64) {
+                const int r = rb + lane;
+                if (r < total) {
+                    // owner: the last lane whose exclusive offset is <= r
+                    int lo = 0, hi = 63;
+#pragma unroll
+                    for (int it = 0; it < 6; it++) {
+                        const int mid = (lo + hi + 1) >> 1;
+                        if (st[mid * 4 + 3].w <= r) lo = mid; else hi = mid - 1;
+                    }
+                    const int4 ow = st[lo * 4 + 3];
+                    const int opoly = ow.x, one = ow.y, y = ow.z + (r - ow.w);
+                    const unsigned id = (unsigned)opoly + 1u;
+                    int beg, end, zs, zi;
+                    bool ok;
+                    if (one <= 3) {
+                        Edge4 oe[3];
+#pragma unroll
+                        for (int e = 0; e < 3; e++) {
+                            const int4 q = st[lo * 4 + e];
+                            oe[e].xy1 = q.x; oe[e].xy2 = q.y; oe[e].z0 = q.z; oe[e].zi = q.w;
+                        }
+                        ok = depth_row3(oe, one, y, beg, end, zs, zi);
+                    } else {
+                        ok = depth_row_mem(a.edges, ESZ, a.np, opoly, one, y, beg, end, zs, zi);
+                    }
+                    if (ok) {
+                        const int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
+                        if (xa <= xb) {
+                            frags += (unsigned long long)(xb - xa + 1);
+                            unsigned long long *krow = keys + (y - ty0) * TW - tx0;
+                            int z = wadd(zs, wmul(xa - beg, zi));
+                            for (int x = xa; x <= xb; x++) {
+                                atomicMin(&krow[x], depth_key(z >> 16, id));
+                                z = wadd(z, zi);
+                            }
+                        }
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
         }
 
         // large polygons: the wave takes them one after another
@@ -1174,35 +1399,66 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     }
     __syncthreads();
 
-    // ---- colour pass + tile out
+    // ---- colour pass + tile out.  Pixels are taken four at a time per lane so that the
+    // four winners' headers and edge coordinates are fetched together (one memory round
+    // trip for the group, a second one for the winning edges' values).
     unsigned long long qrows = 0;
-    for (int p = t; p < TW * TH; p += RASTER_THREADS) {
-        const int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
-        if (gx >= a.W || gy >= a.H) continue;
-        const unsigned long long k = keys[p];
-        const unsigned id = (unsigned)k;
-        const size_t g = (size_t)gy * a.W + gx;
-        if (id == 0u) {
-            if (a.clear_pending) { a.zbuf[g] = INT_MAX; a.cbuf[g] = a.clear_colour; }
-            continue;
-        }
-        const int poly = (int)(id - 1u);
-        const int4 h = ((const int4 *)a.hdr)[poly];
-        const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff, ptex = (h.w >> 16) & 0xff;
-        int c = h.z;
-        if (NA > 1 && kind != KIND_FLAT) {
-            int S[NA], E[NA], I[NA], beg = 0, end = 0;
-            row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E);
-            int span = end - beg;
-            if (span == 0) span = 1;
-            const double rs = drcp(span);
+    constexpr int CG = 4;
+    for (int p0 = t; p0 < TW * TH; p0 += RASTER_THREADS * CG) {
+        unsigned long long kk[CG];
+        int4 hh[CG];
+        int2 xy[CG][3];
 #pragma unroll
-            for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
-            if (NA == 6 && kind >= KIND_TEX_LIN && ((I[1 % NA] | I[2 % NA] | I[3 % NA]) != 0)) qrows++;
-            c = pixel_colour<NA>(a, h, poly, gx, gy, beg, end, S, I, gx - beg);
+        for (int g = 0; g < CG; g++) {
+            const int p = p0 + g * RASTER_THREADS;
+            kk[g] = p < TW * TH ? keys[p] : 0ull;
+            hh[g] = zero4;
+#pragma unroll
+            for (int e = 0; e < 3; e++) xy[g][e] = make_int2(0, 0);
         }
-        a.zbuf[g] = (int)((unsigned)(k >> 32) ^ 0x80000000u);
-        a.cbuf[g] = c;
+#pragma unroll
+        for (int g = 0; g < CG; g++) {
+            const unsigned id = (unsigned)kk[g];
+            if (id != 0u) {
+                const int poly = (int)(id - 1u);
+                hh[g] = ((const int4 *)a.hdr)[poly];
+                if (NA > 1) {
+#pragma unroll
+                    for (int e = 0; e < 3; e++) xy[g][e] = *(const int2 *)(a.edges + ((size_t)e * a.np + poly) * ESZ);
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < CG; g++) {
+            const int p = p0 + g * RASTER_THREADS;
+            if (p >= TW * TH) continue;
+            const int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
+            if (gx >= a.W || gy >= a.H) continue;
+            const unsigned long long k = kk[g];
+            const unsigned id = (unsigned)k;
+            const size_t gi = (size_t)gy * a.W + gx;
+            if (id == 0u) {
+                if (a.clear_pending) { a.zbuf[gi] = INT_MAX; a.cbuf[gi] = a.clear_colour; }
+                continue;
+            }
+            const int poly = (int)(id - 1u);
+            const int4 h = hh[g];
+            const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff;
+            int c = h.z;
+            if (NA > 1 && kind != KIND_FLAT) {
+                int S[NA], E[NA], I[NA], beg = 0, end = 0;
+                row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E, xy[g]);
+                int span = end - beg;
+                if (span == 0) span = 1;
+                const double rs = drcp(span);
+#pragma unroll
+                for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+                if (NA == 6 && kind >= KIND_TEX_LIN && ((I[1 % NA] | I[2 % NA] | I[3 % NA]) != 0)) qrows++;
+                c = pixel_colour<NA>(a, h, poly, gx, gy, beg, end, S, I, gx - beg);
+            }
+            a.zbuf[gi] = (int)((unsigned)(k >> 32) ^ 0x80000000u);
+            a.cbuf[gi] = c;
+        }
     }
 
     // counters: one atomic per wave
@@ -1249,6 +1505,14 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
 {
     if (a.np <= 0) return;
     dim3 g((a.np + SETUP_THREADS - 1) / SETUP_THREADS), b(SETUP_THREADS);
+    if (!screen && a.queue) g = dim3((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, QUEUES);
+    if (!screen && a.queue) {
+        // fast kernel for unclipped triangles; it queues the rest for the general kernel
+        dim3 gf((a.np + 255) / 256), bf(256);
+        if (dim == 3) hipLaunchKernelGGL((setup_fast_kernel<3>), gf, bf, 0, s, a);
+        else if (dim == 6) hipLaunchKernelGGL((setup_fast_kernel<6>), gf, bf, 0, s, a);
+        else hipLaunchKernelGGL((setup_fast_kernel<8>), gf, bf, 0, s, a);
+    }
     if (screen) {
         if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, true>), g, b, 0, s, a);
         else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, true>), g, b, 0, s, a);
