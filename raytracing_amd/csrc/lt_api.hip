@@ -15,6 +15,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// small device scratch: order flag (first 256 bytes), then the setup sub-queue counters
+constexpr size_t kScratchBytes = 256 + (size_t)QUEUES * QUEUE_COUNT_STRIDE * sizeof(unsigned);
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -37,7 +40,7 @@ struct lt_ctx {
     int order_mode = 0;                // LT_ORDER_AUTO / ALWAYS / NEVER
     int *order_flag = nullptr;         // device
     // per-submit workspace (grown on demand, reused)
-    DevBuf view, hdr, edges, prp, list, tcount, toffset, tcursor;
+    DevBuf view, hdr, edges, prp, list, tcount, toffset, tcursor, queue;
     DevBuf s_verts, s_polys, s_aux, s_pv;      // staging for host-pointer submits
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
@@ -155,9 +158,12 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if ((rc = ensure(c, c->tcount, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
     if ((rc = ensure(c, c->toffset, (size_t)(c->ntiles + 1) * sizeof(unsigned)))) return rc;
     if ((rc = ensure(c, c->tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
+    const unsigned qcap = setup_queue_cap(np);
+    if (!screen && (rc = ensure(c, c->queue, (size_t)qcap * QUEUES * sizeof(unsigned)))) return rc;
 
     HIPCHK(c, hipMemsetAsync(c->tcount.p, 0, (size_t)c->ntiles * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->order_flag, (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0, 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->order_flag, 0, kScratchBytes, c->stream));
+    if (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) HIPCHK(c, hipMemsetAsync(c->order_flag, 1, 1, c->stream));
     if (screen) { if ((rc = mark(c))) return rc; if ((rc = mark(c))) return rc; }   // no transform stage
     // (object mode: lt_submit_object_dev has recorded the marks around the transform)
 
@@ -173,6 +179,10 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.hdr = (PrimHdr *)c->hdr.p; sa.edges = (int *)c->edges.p;
     sa.prp = want_prp ? (int *)c->prp.p : nullptr;
     sa.order_flag = c->order_flag; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
+    // object batches: unclipped triangles take the fast kernel, the rest go through sub-queues
+    sa.queue = screen ? nullptr : (unsigned *)c->queue.p;
+    sa.queue_count = (unsigned *)(c->order_flag + 64);      // behind the order flag in the small device scratch
+    sa.queue_cap = qcap;
     sa.status = c->status;
     launch_setup(c->stream, dim, screen, sa);
     if ((rc = mark(c))) return rc;
@@ -259,8 +269,8 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     CREATECHK(hipMalloc((void **)&c->zbuf, n * sizeof(int)));
     CREATECHK(hipMalloc((void **)&c->status, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMemset(c->status, 0, sizeof(Status) * STATUS_SLOTS));
-    CREATECHK(hipMalloc((void **)&c->order_flag, 256));
-    CREATECHK(hipMemset(c->order_flag, 0, 256));
+    CREATECHK(hipMalloc((void **)&c->order_flag, kScratchBytes));
+    CREATECHK(hipMemset(c->order_flag, 0, kScratchBytes));
     CREATECHK(hipMalloc((void **)&c->tex_ptr_d, sizeof(int *) * LT_MAX_TEXTURES));
     CREATECHK(hipMalloc((void **)&c->tex_log_d, sizeof(int) * LT_MAX_TEXTURES));
     CREATECHK(hipMemset((void *)c->tex_ptr_d, 0, sizeof(int *) * LT_MAX_TEXTURES));
@@ -276,7 +286,7 @@ int lt_ctx_destroy(lt_ctx *c)
     if (!c) return LT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->view, &c->hdr, &c->edges, &c->prp, &c->list, &c->tcount, &c->toffset, &c->tcursor,
+    DevBuf *bufs[] = {&c->view, &c->hdr, &c->edges, &c->prp, &c->list, &c->tcount, &c->toffset, &c->tcursor, &c->queue,
                       &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);

@@ -1006,6 +1006,9 @@ __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, 
     return true;
 }
 
+// lane `l` of v, l wave-uniform
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 __device__ __forceinline__ unsigned long long depth_key(int z, unsigned id)
 {
     return ((unsigned long long)((unsigned)z ^ 0x80000000u) << 32) | id;
@@ -1359,18 +1362,20 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
             __builtin_amdgcn_wave_barrier();
         }
 
-        // large polygons: the wave takes them one after another
+        // large polygons: the wave takes them one after another.  The polygon's lane and
+        // the row number are wave-uniform, so the broadcasts are register reads
+        // (v_readlane), not LDS permutes.
         unsigned long long bigmask = __ballot(big);
         while (bigmask) {
             const int src = __ffsll((long long)bigmask) - 1;
             bigmask &= bigmask - 1;
-            const int bpoly = __shfl(poly, src), bne = __shfl(ne, src);
-            const int br0 = __shfl(r0, src), br1 = __shfl(r1, src);
+            const int bpoly = rdlane(poly, src), bne = rdlane(ne, src);
+            const int br0 = rdlane(r0, src), br1 = rdlane(r1, src);
             Edge4 be[3];
 #pragma unroll
             for (int e = 0; e < 3; e++) {
-                be[e].xy1 = __shfl(ed[e].xy1, src); be[e].xy2 = __shfl(ed[e].xy2, src);
-                be[e].z0 = __shfl(ed[e].z0, src);   be[e].zi = __shfl(ed[e].zi, src);
+                be[e].xy1 = rdlane(ed[e].xy1, src); be[e].xy2 = rdlane(ed[e].xy2, src);
+                be[e].z0 = rdlane(ed[e].z0, src);   be[e].zi = rdlane(ed[e].zi, src);
             }
             const unsigned id = (unsigned)bpoly + 1u;
             // rows of the tile are at most TH <= 64: lane l evaluates row br0 + l
@@ -1383,17 +1388,17 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                                   : depth_row_mem(a.edges, ESZ, a.np, bpoly, bne, y, beg, end, zs, zi);
                 if (!ok) { beg = 0; end = -1; }
             }
-            const int nrows = br1 - br0;
+            // depth at this lane's pixel column if the span started there: z = zc + x*zi
             const int x = tx0 + lane;                       // TW == 64: one pixel column per lane
+            const int zc = wsub(zs, wmul(beg, zi));
+            const int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
+            if (xa <= xb) frags += (unsigned long long)(xb - xa + 1);
+            const int nrows = br1 - br0;
+            unsigned long long *kcol = keys + (br0 - ty0) * TW + lane;
             for (int rr = 0; rr < nrows; rr++) {
-                const int rbeg = __shfl(beg, rr), rend = __shfl(end, rr);
-                const int rzs = __shfl(zs, rr), rzi = __shfl(zi, rr);
-                const bool in = x >= rbeg && x <= rend;
-                if (in) atomicMin(&keys[(br0 + rr - ty0) * TW + lane], depth_key(wadd(rzs, wmul(x - rbeg, rzi)) >> 16, id));
-                if (lane == 0) {
-                    int xa = max(rbeg, tx0), xb = min(rend, tx0 + TW - 1);
-                    if (xa <= xb) frags += (unsigned long long)(xb - xa + 1);
-                }
+                const int rbeg = rdlane(beg, rr), rend = rdlane(end, rr);
+                const int rzc = rdlane(zc, rr), rzi = rdlane(zi, rr);
+                if (x >= rbeg && x <= rend) atomicMin(&kcol[rr * TW], depth_key(wadd(rzc, wmul(x, rzi)) >> 16, id));
             }
         }
     }
