@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Benchmark of the polygon rasterization path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2-small|c2-large|c3-lin]
+  python bench.py --gpus N --steps K --warmup W [--workload c2-small|c2-large|c3-lin|c5]
+                  [--split frames|bands]
 
 One step = one frame: clear + one object of `--tris` synthetic triangles (transform,
 setup, binning, Z-buffered fill), inputs resident in HBM before the timed region.  With
 N > 1 (launched by torch.distributed.run, one rank per GPU) every rank renders its own
 frames of the same size (frame-parallel, no collective on the data path; weak scaling)
-and `value` is the whole job's triangles per second.
+and `value` is the whole job's triangles per second.  `--split bands` is the sort-first
+mode for one huge frame: every rank sets up the same triangles, draws its band of rows,
+and rank 0 gathers the bands (point-to-point over RCCL) inside the timed step; the work is
+fixed, so that mode reports strong scaling.
 
 Rank 0 prints one JSON line.  `roofline` is for the slowest kernel of the step:
 algorithmic bytes of one frame (160 B per triangle + 8 B per pixel) over that kernel's
@@ -39,6 +43,8 @@ def make_scene(workload, tris):
         return S.gen_c2(tris, 1920, 1080, 10, radius=128)
     if workload == "c3-lin":
         return S.gen_c3(tris, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=100)
+    if workload == "c5":
+        return S.gen_c2(tris, 16384, 16384, 13, radius=16, seed=0xC0FFEE05)
     raise SystemExit(f"unknown workload {workload}")
 
 
@@ -81,6 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2-small")
     ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--split", default="frames", choices=["frames", "bands"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
     args = ap.parse_args()
 
@@ -92,7 +99,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from raytracing_amd import gpu as G
+    from raytracing_amd import bands as B, gpu as G
 
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -109,10 +116,23 @@ def main():
     for h, (tex, lg) in enumerate(sc.textures):
         ctx.texture_upload(h, tex, lg)
 
+    bands = args.split == "bands"
+    if bands:
+        # the frame lives in torch tensors so that the gather can address it
+        f_c = torch.empty((sc.height, sc.width), dtype=torch.int32, device=dev)
+        f_z = torch.empty((sc.height, sc.width), dtype=torch.int32, device=dev)
+        ctx.bind_framebuffer(f_c, f_z)
+        y0, y1 = B.band_rows(rank, world, sc.height)
+        if y0 < y1:
+            ctx.set_band(y0, y1)
+
     def step():
-        ctx.clear(0)
-        ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux,
-                              matrix=sc.matrix, force_linear=sc.force_linear, max_edges=3)
+        if not bands or y0 < y1:
+            ctx.clear(0)
+            ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux,
+                                  matrix=sc.matrix, force_linear=sc.force_linear, max_edges=3)
+        if bands:
+            B.gather_bands([f_c, f_z], rank, world, sc.height)
 
     for _ in range(args.warmup):
         step()
@@ -144,9 +164,13 @@ def main():
     stages, submits = ctx.stage_ms()
     counters = ctx.counters()
     ctx.set_profiling(False)
+    frags = torch.tensor([counters["fragments"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(frags)                  # bands: the frame's total; frames: all ranks' frames
+    frags = int(frags.item())
 
     if rank == 0:
-        total_tris = sc.n_polys * args.steps * world
+        total_tris = sc.n_polys * args.steps * (1 if bands else world)
         frame_bytes = BYTES_PER_TRI * sc.n_polys + BYTES_PER_PIXEL * sc.width * sc.height
         dom = max(stages, key=lambda k: stages[k])
         dom_ms = stages[dom] / max(submits, 1)
@@ -160,7 +184,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt_max / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if bands else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
@@ -168,9 +192,10 @@ def main():
                                    f"{sc.width}x{sc.height}, one frame per step per GPU"
                        if args.workload.startswith("c2") else
                        f"{args.workload}: {sc.n_polys} textured triangles per frame at {sc.width}x{sc.height}",
-                       "parallelism": f"frame-parallel x{world}", "tile": f"{64}x{32}"},
-            "mfragments_per_s": round(counters["fragments"] * world / dt_max / 1e6, 3),
-            "fragments_per_frame": counters["fragments"] // max(args.steps, 1),
+                       "parallelism": (f"sort-first row bands x{world}, bands gathered to rank 0" if bands
+                                       else f"frame-parallel x{world}"), "tile": f"{64}x{32}"},
+            "mfragments_per_s": round(frags / dt_max / 1e6, 3),
+            "fragments_per_frame": frags // max(args.steps, 1) // (1 if bands else world),
             "stage_ms_per_frame": {k: round(v / max(submits, 1), 4) for k, v in stages.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,

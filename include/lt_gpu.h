@@ -109,6 +109,19 @@ int lt_flush(lt_ctx *ctx);
 int lt_readback(lt_ctx *ctx, int32_t *colour, int32_t *depth);
 /* Device addresses of the frame, valid until lt_ctx_destroy; contents are current after lt_flush. */
 int lt_framebuffer(lt_ctx *ctx, int32_t **d_colour, int32_t **d_depth);
+/* Draw into caller-owned device arrays int32[height][width] (both, or both NULL to go
+ * back to the context's own frame) instead of the arrays lt_ctx_create allocated: the
+ * counterpart of handing the reference other G_c_buffer / G_z_buffer pointers
+ * (GraphicsBase.cpp:35-42).  Flushes first.  The arrays must stay valid while bound; their
+ * contents are taken as the current frame (lt_clear still clears). */
+int lt_bind_framebuffer(lt_ctx *ctx, int32_t *d_colour, int32_t *d_depth);
+/* Sort-first split of one frame over several contexts: this context draws only rows
+ * [y0, y1) of the screen.  Clipping and every interpolant still refer to the whole screen
+ * (GI_scan's spans live in one row each, GraphicsPoly.cpp:124-200, so rows are
+ * independent once the edges are set up); rows outside the band are left untouched or
+ * cleared, never drawn.  The fragment counters of the bands of one frame add up to the
+ * whole frame's.  Default: the whole screen.  No counterpart in the reference. */
+int lt_set_band(lt_ctx *ctx, int y0, int y1);
 int lt_get_counters(lt_ctx *ctx, lt_counters *out);   /* implies lt_flush */
 int lt_reset_counters(lt_ctx *ctx);
 

@@ -29,7 +29,9 @@ struct lt_ctx {
     int device = 0;
     int W = 0, H = 0, tiles_x = 0, tiles_y = 0, ntiles = 0;
     hipStream_t stream = nullptr;
-    int *cbuf = nullptr, *zbuf = nullptr;
+    int *cbuf = nullptr, *zbuf = nullptr;          // the frame being drawn (own or bound)
+    int *own_cbuf = nullptr, *own_zbuf = nullptr;  // allocated by lt_ctx_create
+    int band_y0 = 0, band_y1 = 0;                  // rows this context draws
     bool clear_pending = false;
     int clear_colour = 0;
     bool frame_defined = false;
@@ -183,6 +185,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.queue = screen ? nullptr : (unsigned *)c->queue.p;
     sa.queue_count = (unsigned *)(c->order_flag + 64);      // behind the order flag in the small device scratch
     sa.queue_cap = qcap;
+    sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
     sa.status = c->status;
     launch_setup(c->stream, dim, screen, sa);
     if ((rc = mark(c))) return rc;
@@ -213,6 +216,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     ra.prp = want_prp ? (const int *)c->prp.p : nullptr; ra.log_focus = log_focus;
     ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
     ra.order_flag = c->order_flag;
+    ra.band_y0 = c->band_y0; ra.band_y1 = c->band_y1;
     ra.status = c->status;
     launch_raster(c->stream, na, ra);
     if (dim == 8 && c->order_mode != LT_ORDER_NEVER) HIPCHK(c, launch_ordered(c->stream, ra));
@@ -252,6 +256,7 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     lt_ctx *c = new lt_ctx();
     c->device = device;
     c->W = width; c->H = height;
+    c->band_y0 = 0; c->band_y1 = height;
     c->tiles_x = (width + TW - 1) / TW; c->tiles_y = (height + TH - 1) / TH;
     c->ntiles = c->tiles_x * c->tiles_y;
     size_t n = (size_t)width * height;
@@ -265,8 +270,9 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
         }                                                                                                 \
     } while (0)
     CREATECHK(hipSetDevice(device));
-    CREATECHK(hipMalloc((void **)&c->cbuf, n * sizeof(int)));
-    CREATECHK(hipMalloc((void **)&c->zbuf, n * sizeof(int)));
+    CREATECHK(hipMalloc((void **)&c->own_cbuf, n * sizeof(int)));
+    CREATECHK(hipMalloc((void **)&c->own_zbuf, n * sizeof(int)));
+    c->cbuf = c->own_cbuf; c->zbuf = c->own_zbuf;
     CREATECHK(hipMalloc((void **)&c->status, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMemset(c->status, 0, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMalloc((void **)&c->order_flag, kScratchBytes));
@@ -292,8 +298,8 @@ int lt_ctx_destroy(lt_ctx *c)
         if (b->p) (void)hipFree(b->p);
     for (int i = 0; i < LT_MAX_TEXTURES; i++)
         if (c->tex_data[i]) (void)hipFree(c->tex_data[i]);
-    if (c->cbuf) (void)hipFree(c->cbuf);
-    if (c->zbuf) (void)hipFree(c->zbuf);
+    if (c->own_cbuf) (void)hipFree(c->own_cbuf);
+    if (c->own_zbuf) (void)hipFree(c->own_zbuf);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->status) (void)hipFree(c->status);
     if (c->order_flag) (void)hipFree(c->order_flag);
@@ -326,6 +332,27 @@ int lt_set_list_capacity(lt_ctx *c, uint64_t refs)
 {
     if (!c) return LT_ERR_ARG;
     c->list_capacity_user = refs;
+    return LT_OK;
+}
+
+int lt_set_band(lt_ctx *c, int y0, int y1)
+{
+    if (!c) return LT_ERR_ARG;
+    if (y0 < 0 || y1 > c->H || y0 >= y1) return fail(c, LT_ERR_ARG, "lt_set_band: rows [%d, %d) outside [0, %d)", y0, y1, c->H);
+    c->band_y0 = y0; c->band_y1 = y1;
+    return LT_OK;
+}
+
+int lt_bind_framebuffer(lt_ctx *c, int32_t *d_colour, int32_t *d_depth)
+{
+    if (!c) return LT_ERR_ARG;
+    if ((d_colour == nullptr) != (d_depth == nullptr)) return fail(c, LT_ERR_ARG, "lt_bind_framebuffer: give both arrays or neither");
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = lt_flush(c))) return rc;            // queued work and a pending clear go to the frame they were issued for
+    c->cbuf = d_colour ? d_colour : c->own_cbuf;
+    c->zbuf = d_depth ? d_depth : c->own_zbuf;
+    c->frame_defined = true;                      // the memory holds whatever its owner left there
     return LT_OK;
 }
 

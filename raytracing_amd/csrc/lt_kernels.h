@@ -75,6 +75,7 @@ struct SetupArgs {
     int *order_flag;         // device word raised when a textured polygon's vertex lights differ
     int detect_order;
     int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
+    int band_y0, band_y1;    // rows [band_y0, band_y1) are drawn by this context (whole screen: 0, H)
     Status *status;
 };
 
@@ -95,6 +96,7 @@ struct RasterArgs {
     const int *order_flag;   // see ordered_kernel
     const int *const *tex_ptr;     // device table of texture base pointers
     const int *tex_log;            // device table of log sizes
+    int band_y0, band_y1;          // rows drawn by this context
     Status *status;
 };
 

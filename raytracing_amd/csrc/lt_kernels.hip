@@ -389,7 +389,9 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
             drawn = true;
             const int miny = min(t[1].v[1], min(t[2].v[1], t[3].v[1])), maxy = max(t[1].v[1], max(t[2].v[1], t[3].v[1]));
             const int minx = min(t[1].v[0], min(t[2].v[0], t[3].v[0])), maxx = max(t[1].v[0], max(t[2].v[0], t[3].v[0]));
-            if (miny < maxy) {
+            // rows outside the band of this context are another context's to draw
+            const int by0 = max(miny, a.band_y0), by1 = min(maxy, a.band_y1);
+            if (by0 < by1) {
                 store_edge_record<DIM>(a, poly, 0, t[1], t[2]);
                 store_edge_record<DIM>(a, poly, 1, t[2], t[3]);
                 store_edge_record<DIM>(a, poly, 2, t[3], t[1]);
@@ -398,7 +400,7 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
                     const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
                     col = cl_light(colour, ax.x, ax.y, ax.z);
                 }
-                hdr = make_int4(miny | (maxy << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
+                hdr = make_int4(by0 | (by1 << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
             }
         }
         if (!slow) ((int4 *)a.hdr)[poly] = hdr;
@@ -740,6 +742,12 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 
     bool reached_fill = draw;
     if (draw && !(miny < maxy && ne > 0)) draw = false;
+    if (draw) {
+        // rows outside the band of this context are another context's to draw
+        miny = max(miny, a.band_y0);
+        maxy = min(maxy, a.band_y1);
+        if (!(miny < maxy)) draw = false;
+    }
 
     if (draw) {
         int col = colour;
@@ -1144,7 +1152,8 @@ __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
     const int W = a.W;
     int *zt = band_lds, *ct = band_lds + R * W;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int y0 = blockIdx.x * R, y1 = min(y0 + R, a.H);
+    const int y0 = max(blockIdx.x * R, a.band_y0), y1 = min(min(blockIdx.x * R + R, a.H), a.band_y1);
+    if (y0 >= y1) return;
     const int npx = (y1 - y0) * W;
     for (int p = t; p < npx; p += 256) {
         const size_t g = (size_t)y0 * W + p;
@@ -1241,6 +1250,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     if ((unsigned long long)lbeg + lcnt > a.list_capacity)      // list overflow (reported by the scan): stay inside the list
         lcnt = a.list_capacity > lbeg ? (unsigned)(a.list_capacity - lbeg) : 0u;
     if (lcnt == 0 && !a.clear_pending) return;       // untouched tile of a frame that is already in HBM
+    if (ty0 + TH <= a.band_y0 || ty0 >= a.band_y1) return;      // outside the band this context draws
     if (NA == 6 && *a.order_flag) return;            // the draw-order kernel fills this batch
 
     // ---- tile in: depth only
@@ -1260,8 +1270,11 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     // pieces do not wait for the header: planes 0..2 of the pool exist for every polygon.
     const unsigned rounds = (lcnt + RASTER_THREADS - 1) / RASTER_THREADS;
     const int4 zero4 = make_int4(0, 0, 0, 0);
-    int poly_c = t < lcnt ? (int)a.tile_list[lbeg + t] : -1;
-    int poly_n = (unsigned)(RASTER_THREADS + t) < lcnt ? (int)a.tile_list[lbeg + RASTER_THREADS + t] : -1;
+    // list entries are dealt to the waves in turn (entry e of a round goes to wave e % 4),
+    // so a short list or a short last round still gives every wave its share
+    const unsigned slot = (unsigned)(lane * (RASTER_THREADS / 64) + (t >> 6));
+    int poly_c = slot < lcnt ? (int)a.tile_list[lbeg + slot] : -1;
+    int poly_n = RASTER_THREADS + slot < lcnt ? (int)a.tile_list[lbeg + RASTER_THREADS + slot] : -1;
     int4 h_c = zero4, e0_c = zero4, e1_c = zero4, e2_c = zero4;
     if (poly_c >= 0) {
         h_c = ((const int4 *)a.hdr)[poly_c];
@@ -1277,7 +1290,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
             e1_n = *(const int4 *)(a.edges + ((size_t)1 * a.np + poly_n) * ESZ);
             e2_n = *(const int4 *)(a.edges + ((size_t)2 * a.np + poly_n) * ESZ);
         }
-        const unsigned li2 = (rd + 2) * RASTER_THREADS + t;
+        const unsigned li2 = (rd + 2) * RASTER_THREADS + slot;
         const int poly_nn = li2 < lcnt ? (int)a.tile_list[lbeg + li2] : -1;
 
         const int poly = poly_c;

@@ -82,6 +82,17 @@ class Context:
             self._chk(rc)
         return c, z
 
+    def bind_framebuffer(self, d_colour, d_depth):
+        """draw into torch int32 CUDA tensors [H][W] (None, None: back to the context's own frame)"""
+        for t in (d_colour, d_depth):
+            assert t is None or tuple(t.shape) == (self.h, self.w)
+        self._chk(self.L.lt_bind_framebuffer(self.h_ctx, _dp(d_colour), _dp(d_depth)))
+        self._bound = (d_colour, d_depth)          # keep the tensors alive while bound
+
+    def set_band(self, y0, y1):
+        """this context draws only rows [y0, y1) of the screen"""
+        self._chk(self.L.lt_set_band(self.h_ctx, y0, y1))
+
     def counters(self):
         cs = _lib.Counters()
         self._chk(self.L.lt_get_counters(self.h_ctx, C.byref(cs)))

@@ -1,0 +1,146 @@
+"""Sort-first row bands on the GPU: a frame drawn band by band (lt_set_band) equals the
+frame drawn at once and the CPU checker's, bit for bit, and the bands' fragment counts add
+up; lt_bind_framebuffer draws into caller-owned device memory."""
+import numpy as np
+import pytest
+
+from raytracing_amd import bands as B, scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import oracle.port as P
+    from raytracing_amd import gpu as G
+    return P, G
+
+
+def _oracle(P, sc, clear):
+    orc = P.Oracle(sc.width, sc.height)
+    for h, (tex, lg) in enumerate(sc.textures):
+        orc.set_texture(h, tex, lg)
+    orc.clear(*clear)
+    orc.reset_counters()
+    orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type,
+                     sc.log_focus, sc.force_linear)
+    return orc.cbuf().copy(), orc.zbuf().copy(), orc.counters()
+
+
+def _banded(P, G, sc, bands, clear):
+    ctx = G.Context(sc.width, sc.height)
+    c = np.full((sc.height, sc.width), -1, np.int32)
+    z = np.full((sc.height, sc.width), -1, np.int32)
+    frags = 0
+    for y0, y1 in bands:
+        if y0 >= y1:
+            continue
+        ctx.set_band(y0, y1)
+        ctx.clear(P.cl_light(*clear))
+        ctx.reset_counters()
+        ctx.submit_scene(sc)
+        bc, bz = ctx.readback()
+        c[y0:y1], z[y0:y1] = bc[y0:y1], bz[y0:y1]
+        frags += ctx.counters()["fragments"]
+    ctx.close()
+    return c, z, frags
+
+
+CLEAR = (0x102030, 255, 255, 255)
+
+
+@pytest.mark.parametrize("world,align", [(2, 32), (3, 32), (8, 32), (5, 1)])
+def test_shaded_bands_equal_whole_frame(env, world, align):
+    P, G = env
+    sc = S.gen_c2(20000, 640, 480, 9, radius=24, seed=77)
+    oc, oz, ocn = _oracle(P, sc, CLEAR)
+    c, z, frags = _banded(P, G, sc, B.all_bands(world, sc.height, align), CLEAR)
+    assert (z == oz).all() and (c == oc).all()
+    assert frags == ocn["fragments"]
+
+
+def test_fuzz_polygons_in_bands(env):
+    """clipped, many-edged and degenerate polygons; bands that cut through tiles"""
+    P, G = env
+    for seed in range(4):
+        sc = S.gen_fuzz_polys(80, 160, 120, 7, 300 + seed)
+        oc, oz, ocn = _oracle(P, sc, CLEAR)
+        c, z, frags = _banded(P, G, sc, [(0, 13), (13, 14), (14, 77), (77, 120)], CLEAR)
+        assert (z == oz).all() and (c == oc).all()
+        assert frags == ocn["fragments"]
+
+
+def test_textured_order_dependent_bands(env):
+    """the draw-order kernel (light advancing on depth passes) restricted to bands"""
+    P, G = env
+    sc = S.gen_fuzz_polys(80, 160, 120, 7, 901, render_type=S.M_TEXTURED, textured=True, equal_lights=False,
+                          zrange=(12, 2000))
+    oc, oz, ocn = _oracle(P, sc, CLEAR)
+    c, z, frags = _banded(P, G, sc, [(0, 50), (50, 51), (51, 120)], CLEAR)
+    assert (z == oz).all() and (c == oc).all()
+    assert frags == ocn["fragments"]
+
+
+def test_band_leaves_other_rows_alone(env):
+    P, G = env
+    sc = S.gen_c2(5000, 320, 256, 8, radius=16, seed=5)
+    ctx = G.Context(sc.width, sc.height)
+    ctx.clear(0x111111)
+    ctx.flush()                                   # the whole frame now holds the clear colour
+    ctx.set_band(64, 128)
+    ctx.submit_scene(sc)
+    c, z = ctx.readback()
+    outside = np.r_[0:64, 128:256]
+    assert (c[outside] == 0x111111).all() and (z[outside] == 2**31 - 1).all()
+    assert (c[64:128] != 0x111111).any()
+    with pytest.raises(G.LtError):
+        ctx.set_band(10, 10)
+    with pytest.raises(G.LtError):
+        ctx.set_band(0, 257)
+
+
+def test_bind_framebuffer_and_gather_in_place(env):
+    """two contexts stand for two ranks: each draws its band into its own torch tensors;
+    copying the second band's rows into the first frame is what the gather does"""
+    import torch
+    P, G = env
+    sc = S.gen_c2(20000, 640, 480, 9, radius=24, seed=78)
+    oc, oz, _ = _oracle(P, sc, CLEAR)
+    frames = []
+    for r in range(2):
+        y0, y1 = B.band_rows(r, 2, sc.height)
+        c = torch.full((sc.height, sc.width), -1, dtype=torch.int32, device="cuda")
+        z = torch.full((sc.height, sc.width), -1, dtype=torch.int32, device="cuda")
+        ctx = G.Context(sc.width, sc.height)
+        ctx.bind_framebuffer(c, z)
+        ctx.set_band(y0, y1)
+        ctx.clear(P.cl_light(*CLEAR))
+        ctx.submit_scene(sc)
+        ctx.flush()
+        ctx.close()
+        frames.append((c, z, y0, y1))
+    c0, z0, _, _ = frames[0]
+    c1, z1, y0, y1 = frames[1]
+    c0[y0:y1].copy_(c1[y0:y1])
+    z0[y0:y1].copy_(z1[y0:y1])
+    assert (c0.cpu().numpy() == oc).all() and (z0.cpu().numpy() == oz).all()
+    B.gather_bands([c0, z0], 0, 1, sc.height)     # world size 1: nothing to exchange
+
+
+def test_unbind_returns_to_own_frame(env):
+    import torch
+    P, G = env
+    sc = S.gen_c2(3000, 320, 256, 8, radius=16, seed=6)
+    ctx = G.Context(sc.width, sc.height)
+    ctx.clear(0)
+    ctx.submit_scene(sc)
+    own_c, own_z = ctx.readback()
+    c = torch.zeros((sc.height, sc.width), dtype=torch.int32, device="cuda")
+    z = torch.zeros((sc.height, sc.width), dtype=torch.int32, device="cuda")
+    ctx.bind_framebuffer(c, z)
+    ctx.clear(0x00ff00)
+    ctx.flush()
+    assert (c.cpu().numpy() == 0x00ff00).all() and (z.cpu().numpy() == 2**31 - 1).all()
+    ctx.bind_framebuffer(None, None)
+    c2, z2 = ctx.readback()
+    assert (c2 == own_c).all() and (z2 == own_z).all()
