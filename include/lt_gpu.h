@@ -77,8 +77,15 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out);
 int lt_ctx_destroy(lt_ctx *ctx);
 const char *lt_last_error(lt_ctx *ctx);          /* ctx may be NULL: last creation error */
 
-/* Issue the context's work on an existing hipStream_t (NULL = the default stream). */
+/* The caller's hipStream_t (NULL = the default stream): device inputs of a submit may be
+ * produced on it (each batch waits for what that stream holds at the time of the submit),
+ * lt_transform and the host-array copies run on it.  Results are defined after lt_flush. */
 int lt_set_stream(lt_ctx *ctx, void *hip_stream);
+/* on (default): set-up and binning of a batch run on a stream of the context's own while
+ * the fill of the batch before it runs on another, with two sets of work arrays; draw
+ * order is kept.  off: every kernel is issued on the caller's stream, in order, with one
+ * set in use.  No counterpart in the reference (which draws synchronously). */
+int lt_set_pipelining(lt_ctx *ctx, int on);
 /* Capacity, in (polygon, tile) references, of the per-submit tile lists.  0 = default
  * (64 per polygon, at least 1M). */
 int lt_set_list_capacity(lt_ctx *ctx, uint64_t refs);
@@ -125,10 +132,13 @@ int lt_set_band(lt_ctx *ctx, int y0, int y1);
 int lt_get_counters(lt_ctx *ctx, lt_counters *out);   /* implies lt_flush */
 int lt_reset_counters(lt_ctx *ctx);
 
-/* Stage timing with HIP events on the context's stream (no counterpart in the
- * reference, which has no timers): when on, every submit records events around its
- * kernels.  lt_get_stage_ms implies lt_flush and returns, summed since the last call,
- * the milliseconds of {transform, setup, scan, bin, fill} and the number of submits. */
+/* Stage timing with HIP events on the streams the kernels run on (no counterpart in the
+ * reference, which has no timers).  on = 1: every stage of every submit is bracketed by
+ * events; any other value is a mask of the stages to time (bit k = stage k, e.g. 16 = the
+ * fill only): an event costs a few microseconds of stream time, so time only what is
+ * needed inside a measured region.  lt_get_stage_ms implies lt_flush and returns, summed
+ * since the last call, the milliseconds of {transform, setup, scan, bin, fill} and the
+ * number of submits. */
 #define LT_STAGES 5
 int lt_set_profiling(lt_ctx *ctx, int on);
 int lt_get_stage_ms(lt_ctx *ctx, double ms[LT_STAGES], int *submits);

@@ -14,7 +14,7 @@ EXPORTS = [
     "lt_clear", "lt_flush", "lt_readback", "lt_framebuffer", "lt_get_counters", "lt_reset_counters",
     "lt_texture_upload", "lt_transform", "lt_submit_object", "lt_submit_object_dev",
     "lt_submit_screen_polys", "lt_set_profiling", "lt_get_stage_ms", "lt_set_textured_order",
-    "lt_bind_framebuffer", "lt_set_band",
+    "lt_bind_framebuffer", "lt_set_band", "lt_set_pipelining",
 ]
 
 
@@ -53,6 +53,7 @@ def lib():
     L.lt_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.lt_bind_framebuffer.argtypes = [vp, vp, vp]
     L.lt_set_band.argtypes = [vp, i32, i32]
+    L.lt_set_pipelining.argtypes = [vp, i32]
     L.lt_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.lt_reset_counters.argtypes = [vp]
     L.lt_texture_upload.argtypes = [vp, i32, vp, i32]

@@ -40,9 +40,20 @@ struct lt_ctx {
     uint64_t polys_in = 0;
     uint64_t list_capacity_user = 0;
     int order_mode = 0;                // LT_ORDER_AUTO / ALWAYS / NEVER
-    int *order_flag = nullptr;         // device
-    // per-submit workspace (grown on demand, reused)
-    DevBuf view, hdr, edges, prp, list, tcount, toffset, tcursor, queue;
+    // Per-batch workspace (grown on demand, reused).  There are two sets: the set-up and
+    // binning of a batch (which do not touch the frame) run on `gs` while the fill of the
+    // batch before it runs on `rs`, each batch taking the set the batch two before it used.
+    struct Work {
+        DevBuf hdr, edges, prp, list, tcount, toffset, tcursor, queue, scratch;   // scratch: order flag + sub-queue counters
+        hipEvent_t geom_done = nullptr, raster_done = nullptr;
+        bool in_use = false;
+    } work[2];
+    unsigned batch_no = 0;
+    bool pipelined = true;
+    hipStream_t own_gs = nullptr, own_rs = nullptr;    // internal streams (non-blocking)
+    hipStream_t gs = nullptr, rs = nullptr;            // streams in use: own_* or `stream`
+    hipEvent_t ev_fork = nullptr;
+    DevBuf view;
     DevBuf s_verts, s_polys, s_aux, s_pv;      // staging for host-pointer submits
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
@@ -50,9 +61,12 @@ struct lt_ctx {
     const int **tex_ptr_d = nullptr;
     int *tex_log_d = nullptr;
     // stage timing
-    bool profiling = false;
+    int profiling = 0;                 // bit k: stage k is timed
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
+    struct Span { int stage; size_t begin, end; };      // indices into ev_pool
+    std::vector<Span> spans;
+    int timed_batches = 0;
     double stage_ms[LT_STAGES] = {};
     int stage_submits = 0;
     std::string err;
@@ -81,6 +95,8 @@ int ensure(lt_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return LT_OK;
     if (b.p) {
+        HIPCHK(c, hipStreamSynchronize(c->gs));
+        HIPCHK(c, hipStreamSynchronize(c->rs));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr; b.cap = 0;
@@ -91,31 +107,63 @@ int ensure(lt_ctx *c, DevBuf &b, size_t bytes)
     return LT_OK;
 }
 
-// record an event on the stream (profiling only); events are pooled and reused
-int mark(lt_ctx *c)
+// Stage timing: a timed stage is bracketed by two events on the stream it runs on;
+// events are pooled and reused.  Only the stages named in the profiling mask pay for
+// events (an event costs a few microseconds of stream time).
+int new_event(lt_ctx *c, hipStream_t s, size_t *idx)
 {
-    if (!c->profiling) return LT_OK;
     if (c->ev_used == c->ev_pool.size()) {
         hipEvent_t e;
         HIPCHK(c, hipEventCreate(&e));
         c->ev_pool.push_back(e);
     }
-    HIPCHK(c, hipEventRecord(c->ev_pool[c->ev_used++], c->stream));
+    *idx = c->ev_used++;
+    if (s != (hipStream_t)-1) HIPCHK(c, hipEventRecord(c->ev_pool[*idx], s));
     return LT_OK;
 }
 
-// fold recorded events (groups of LT_STAGES+1 per submit) into stage_ms; stream must be idle
+bool timed(const lt_ctx *c, int stage) { return (c->profiling >> stage) & 1; }
+
+int stage_begin(lt_ctx *c, int stage, hipStream_t s)
+{
+    if (!timed(c, stage)) return LT_OK;
+    lt_ctx::Span sp{stage, 0, 0};
+    // a stage that follows a timed stage on the same stream starts at that stage's end
+    if (stage > 0 && stage < 4 && !c->spans.empty() && c->spans.back().stage == stage - 1) sp.begin = c->spans.back().end;
+    else { int rc = new_event(c, s, &sp.begin); if (rc) return rc; }
+    c->spans.push_back(sp);
+    return LT_OK;
+}
+
+// `recorded`: the end event has been recorded by the callee (index in *recorded)
+int stage_end(lt_ctx *c, int stage, hipStream_t s, const size_t *recorded = nullptr)
+{
+    if (!timed(c, stage)) return LT_OK;
+    if (recorded) { c->spans.back().end = *recorded; return LT_OK; }
+    return new_event(c, s, &c->spans.back().end);
+}
+
+// fold the recorded spans into stage_ms; every stream must be idle
 int collect(lt_ctx *c)
 {
-    for (size_t i = 0; i + LT_STAGES < c->ev_used; i += LT_STAGES + 1) {
-        for (int k = 0; k < LT_STAGES; k++) {
-            float ms = 0.f;
-            HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i + k], c->ev_pool[i + k + 1]));
-            c->stage_ms[k] += ms;
-        }
-        c->stage_submits++;
+    for (const lt_ctx::Span &sp : c->spans) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[sp.begin], c->ev_pool[sp.end]));
+        c->stage_ms[sp.stage] += ms;
     }
+    c->stage_submits += c->timed_batches;
+    c->timed_batches = 0;
+    c->spans.clear();
     c->ev_used = 0;
+    return LT_OK;
+}
+
+// host waits until everything queued by this context has run
+int sync_all(lt_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->gs));
+    HIPCHK(c, hipStreamSynchronize(c->rs));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LT_OK;
 }
 
@@ -131,6 +179,16 @@ int read_status(lt_ctx *c, Status *out)
         const unsigned long long *v = (const unsigned long long *)&s;
         for (int k = 0; k < 8; k++) o[k] += v[k];
     }
+    return LT_OK;
+}
+
+// as ensure(), and a newly allocated array starts at zero
+int ensure_zeroed(lt_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return LT_OK;
+    int rc = ensure(c, b, bytes);
+    if (rc) return rc;
+    HIPCHK(c, hipMemset(b.p, 0, b.cap));
     return LT_OK;
 }
 
@@ -152,22 +210,35 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if (capacity < (1u << 20)) capacity = 1u << 20;
 
     int rc;
-    if ((rc = ensure(c, c->hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
-    if ((rc = ensure(c, c->edges, (size_t)np * emax * edge_ints(na) * sizeof(int)))) return rc;
-    if ((rc = ensure(c, c->list, (size_t)capacity * sizeof(unsigned)))) return rc;
+    lt_ctx::Work &w = c->work[c->batch_no & 1u];
+    hipStream_t gs = c->gs, rs = c->rs;
+    if (c->pipelined) {
+        // the inputs may have been produced on the caller's stream
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(gs, c->ev_fork, 0));
+        // this workspace set is free once the fill of the batch two before this one is done
+        if (w.in_use) HIPCHK(c, hipStreamWaitEvent(gs, w.raster_done, 0));
+    }
+    if ((rc = ensure(c, w.hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
+    if ((rc = ensure(c, w.edges, (size_t)np * emax * edge_ints(na) * sizeof(int)))) return rc;
+    if ((rc = ensure(c, w.list, (size_t)capacity * sizeof(unsigned)))) return rc;
     const bool want_prp = !screen && dim == 8;
-    if (want_prp && (rc = ensure(c, c->prp, (size_t)np * PRP_INTS * sizeof(int)))) return rc;
-    if ((rc = ensure(c, c->tcount, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
-    if ((rc = ensure(c, c->toffset, (size_t)(c->ntiles + 1) * sizeof(unsigned)))) return rc;
-    if ((rc = ensure(c, c->tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
+    if (want_prp && (rc = ensure(c, w.prp, (size_t)np * PRP_INTS * sizeof(int)))) return rc;
+    if ((rc = ensure_zeroed(c, w.tcount, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
+    if ((rc = ensure(c, w.toffset, (size_t)(c->ntiles + 1) * sizeof(unsigned)))) return rc;
+    if ((rc = ensure(c, w.tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
+    if ((rc = ensure_zeroed(c, w.scratch, kScratchBytes))) return rc;
     const unsigned qcap = setup_queue_cap(np);
-    if (!screen && (rc = ensure(c, c->queue, (size_t)qcap * QUEUES * sizeof(unsigned)))) return rc;
+    if (!screen && (rc = ensure(c, w.queue, (size_t)qcap * QUEUES * sizeof(unsigned)))) return rc;
+    int *order_flag = (int *)w.scratch.p;
 
-    HIPCHK(c, hipMemsetAsync(c->tcount.p, 0, (size_t)c->ntiles * sizeof(unsigned), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->order_flag, 0, kScratchBytes, c->stream));
-    if (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) HIPCHK(c, hipMemsetAsync(c->order_flag, 1, 1, c->stream));
-    if (screen) { if ((rc = mark(c))) return rc; if ((rc = mark(c))) return rc; }   // no transform stage
-    // (object mode: lt_submit_object_dev has recorded the marks around the transform)
+    // the transform is applied inside the setup kernel: its stage is empty
+    if ((rc = stage_begin(c, 0, gs))) return rc;
+    if ((rc = stage_end(c, 0, gs))) return rc;
+    if ((rc = stage_begin(c, 1, gs))) return rc;
+    // the tile counts and the sub-queue counters are zero here: allocated so, and the scan
+    // kernel of the batch that used them last has reset them
+    const int order_gen = (int)(c->batch_no % 0x7fffffffu) + 1;
 
     SetupArgs sa{};
     sa.use_matrix = m ? 1 : 0;
@@ -178,50 +249,66 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.max_edges = max_edges;
     sa.W = c->W; sa.H = c->H; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
     sa.emax = emax;
-    sa.hdr = (PrimHdr *)c->hdr.p; sa.edges = (int *)c->edges.p;
-    sa.prp = want_prp ? (int *)c->prp.p : nullptr;
-    sa.order_flag = c->order_flag; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
+    sa.hdr = (PrimHdr *)w.hdr.p; sa.edges = (int *)w.edges.p;
+    sa.prp = want_prp ? (int *)w.prp.p : nullptr;
+    sa.order_flag = order_flag; sa.order_gen = order_gen; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
     // object batches: unclipped triangles take the fast kernel, the rest go through sub-queues
-    sa.queue = screen ? nullptr : (unsigned *)c->queue.p;
-    sa.queue_count = (unsigned *)(c->order_flag + 64);      // behind the order flag in the small device scratch
+    sa.queue = screen ? nullptr : (unsigned *)w.queue.p;
+    sa.queue_count = (unsigned *)(order_flag + 64);      // behind the order flag in the small device scratch
     sa.queue_cap = qcap;
     sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
     sa.status = c->status;
-    launch_setup(c->stream, dim, screen, sa);
-    if ((rc = mark(c))) return rc;
+    launch_setup(gs, dim, screen, sa);
+    if ((rc = stage_end(c, 1, gs))) return rc;
 
-    // the scan mark is recorded inside launch_binning: count belongs to the "scan" stage
+    // count + scan are the "scan" stage, the scatter is the "bin" stage; the event between
+    // them is recorded inside launch_binning
+    if ((rc = stage_begin(c, 2, gs))) return rc;
     hipEvent_t scan_ev = nullptr;
-    if (c->profiling) {
-        if (c->ev_used == c->ev_pool.size()) {
-            hipEvent_t e;
-            HIPCHK(c, hipEventCreate(&e));
-            c->ev_pool.push_back(e);
-        }
-        scan_ev = c->ev_pool[c->ev_used++];
+    size_t scan_idx = 0;
+    if (timed(c, 2) || timed(c, 3)) {
+        if ((rc = new_event(c, (hipStream_t)-1, &scan_idx))) return rc;
+        scan_ev = c->ev_pool[scan_idx];
     }
-    launch_binning(c->stream, (const PrimHdr *)c->hdr.p, np, c->tiles_x, c->ntiles, (unsigned *)c->tcount.p,
-                   (unsigned *)c->toffset.p, (unsigned *)c->tcursor.p, (unsigned *)c->list.p, capacity, c->status,
-                   scan_ev);
-    if ((rc = mark(c))) return rc;
+    launch_binning(gs, (const PrimHdr *)w.hdr.p, np, c->tiles_x, c->ntiles, (unsigned *)w.tcount.p,
+                   (unsigned *)w.toffset.p, (unsigned *)w.tcursor.p, (unsigned *)w.list.p, capacity,
+                   screen ? nullptr : sa.queue_count, c->status, scan_ev);
+    if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
+    if (timed(c, 3)) {
+        lt_ctx::Span sp{3, scan_idx, 0};
+        c->spans.push_back(sp);
+        if ((rc = stage_end(c, 3, gs))) return rc;
+    }
+    if (c->pipelined) {
+        HIPCHK(c, hipEventRecord(w.geom_done, gs));
+        HIPCHK(c, hipStreamWaitEvent(rs, w.geom_done, 0));
+    }
 
     RasterArgs ra{};
-    ra.hdr = (const PrimHdr *)c->hdr.p; ra.edges = (const int *)c->edges.p;
-    ra.tile_offset = (const unsigned *)c->toffset.p; ra.tile_fill = (const unsigned *)c->tcursor.p;
-    ra.tile_list = (const unsigned *)c->list.p; ra.list_capacity = capacity;
+    ra.hdr = (const PrimHdr *)w.hdr.p; ra.edges = (const int *)w.edges.p;
+    ra.tile_offset = (const unsigned *)w.toffset.p; ra.tile_fill = (const unsigned *)w.tcursor.p;
+    ra.tile_list = (const unsigned *)w.list.p; ra.list_capacity = capacity;
     ra.np = np; ra.emax = emax;
     ra.W = c->W; ra.H = c->H; ra.tiles_x = c->tiles_x; ra.tiles_y = c->tiles_y;
     ra.cbuf = c->cbuf; ra.zbuf = c->zbuf;
     ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
-    ra.prp = want_prp ? (const int *)c->prp.p : nullptr; ra.log_focus = log_focus;
+    ra.prp = want_prp ? (const int *)w.prp.p : nullptr; ra.log_focus = log_focus;
     ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
-    ra.order_flag = c->order_flag;
+    ra.order_flag = order_flag; ra.order_gen = order_gen;
+    ra.force_order = (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0;
     ra.band_y0 = c->band_y0; ra.band_y1 = c->band_y1;
     ra.status = c->status;
-    launch_raster(c->stream, na, ra);
-    if (dim == 8 && c->order_mode != LT_ORDER_NEVER) HIPCHK(c, launch_ordered(c->stream, ra));
-    if ((rc = mark(c))) return rc;
+    if ((rc = stage_begin(c, 4, rs))) return rc;
+    launch_raster(rs, na, ra);
+    if (dim == 8 && c->order_mode != LT_ORDER_NEVER) HIPCHK(c, launch_ordered(rs, ra));
+    if ((rc = stage_end(c, 4, rs))) return rc;
     HIPCHK(c, hipGetLastError());
+    if (c->pipelined) {
+        HIPCHK(c, hipEventRecord(w.raster_done, rs));
+        w.in_use = true;
+    }
+    c->batch_no++;
+    if (c->profiling) c->timed_batches++;
 
     c->clear_pending = false;
     c->frame_defined = true;
@@ -275,8 +362,14 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     c->cbuf = c->own_cbuf; c->zbuf = c->own_zbuf;
     CREATECHK(hipMalloc((void **)&c->status, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMemset(c->status, 0, sizeof(Status) * STATUS_SLOTS));
-    CREATECHK(hipMalloc((void **)&c->order_flag, kScratchBytes));
-    CREATECHK(hipMemset(c->order_flag, 0, kScratchBytes));
+    CREATECHK(hipStreamCreateWithFlags(&c->own_gs, hipStreamNonBlocking));
+    CREATECHK(hipStreamCreateWithFlags(&c->own_rs, hipStreamNonBlocking));
+    c->gs = c->own_gs; c->rs = c->own_rs;
+    CREATECHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (lt_ctx::Work &w : c->work) {
+        CREATECHK(hipEventCreateWithFlags(&w.geom_done, hipEventDisableTiming));
+        CREATECHK(hipEventCreateWithFlags(&w.raster_done, hipEventDisableTiming));
+    }
     CREATECHK(hipMalloc((void **)&c->tex_ptr_d, sizeof(int *) * LT_MAX_TEXTURES));
     CREATECHK(hipMalloc((void **)&c->tex_log_d, sizeof(int) * LT_MAX_TEXTURES));
     CREATECHK(hipMemset((void *)c->tex_ptr_d, 0, sizeof(int *) * LT_MAX_TEXTURES));
@@ -291,18 +384,28 @@ int lt_ctx_destroy(lt_ctx *c)
 {
     if (!c) return LT_OK;
     (void)hipSetDevice(c->device);
+    if (c->gs) (void)hipStreamSynchronize(c->gs);
+    if (c->rs) (void)hipStreamSynchronize(c->rs);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->view, &c->hdr, &c->edges, &c->prp, &c->list, &c->tcount, &c->toffset, &c->tcursor, &c->queue,
-                      &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv};
+    DevBuf *bufs[] = {&c->view, &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    for (lt_ctx::Work &w : c->work) {
+        DevBuf *wb[] = {&w.hdr, &w.edges, &w.prp, &w.list, &w.tcount, &w.toffset, &w.tcursor, &w.queue, &w.scratch};
+        for (DevBuf *b : wb)
+            if (b->p) (void)hipFree(b->p);
+        if (w.geom_done) (void)hipEventDestroy(w.geom_done);
+        if (w.raster_done) (void)hipEventDestroy(w.raster_done);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->own_gs) (void)hipStreamDestroy(c->own_gs);
+    if (c->own_rs) (void)hipStreamDestroy(c->own_rs);
     for (int i = 0; i < LT_MAX_TEXTURES; i++)
         if (c->tex_data[i]) (void)hipFree(c->tex_data[i]);
     if (c->own_cbuf) (void)hipFree(c->own_cbuf);
     if (c->own_zbuf) (void)hipFree(c->own_zbuf);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->status) (void)hipFree(c->status);
-    if (c->order_flag) (void)hipFree(c->order_flag);
     if (c->tex_ptr_d) (void)hipFree((void *)c->tex_ptr_d);
     if (c->tex_log_d) (void)hipFree(c->tex_log_d);
     delete c;
@@ -316,8 +419,22 @@ int lt_set_stream(lt_ctx *c, void *hip_stream)
     if (!c) return LT_ERR_ARG;
     int rc = use_device(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = sync_all(c))) return rc;
     c->stream = (hipStream_t)hip_stream;
+    if (!c->pipelined) c->gs = c->rs = c->stream;
+    return LT_OK;
+}
+
+int lt_set_pipelining(lt_ctx *c, int on)
+{
+    if (!c) return LT_ERR_ARG;
+    int rc = use_device(c);
+    if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
+    c->pipelined = on != 0;
+    c->gs = c->pipelined ? c->own_gs : c->stream;
+    c->rs = c->pipelined ? c->own_rs : c->stream;
+    for (lt_ctx::Work &w : c->work) w.in_use = false;
     return LT_OK;
 }
 
@@ -368,7 +485,7 @@ int lt_clear(lt_ctx *c, int32_t lit_colour)
 static int materialize_clear(lt_ctx *c)
 {
     if (c->clear_pending) {
-        launch_fill(c->stream, c->cbuf, c->zbuf, (size_t)c->W * c->H, c->clear_colour);
+        launch_fill(c->rs, c->cbuf, c->zbuf, (size_t)c->W * c->H, c->clear_colour);
         HIPCHK(c, hipGetLastError());
         c->clear_pending = false;
     }
@@ -381,7 +498,7 @@ int lt_flush(lt_ctx *c)
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = materialize_clear(c))) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = sync_all(c))) return rc;
     if ((rc = collect(c))) return rc;
     Status s;
     if ((rc = read_status(c, &s))) return rc;
@@ -440,7 +557,7 @@ int lt_get_counters(lt_ctx *c, lt_counters *out)
     if (!c || !out) return LT_ERR_ARG;
     int rc = use_device(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = sync_all(c))) return rc;
     Status s;
     if ((rc = read_status(c, &s))) return rc;
     out->fragments = s.fragments;
@@ -459,7 +576,9 @@ int lt_reset_counters(lt_ctx *c)
     if (!c) return LT_ERR_ARG;
     int rc = use_device(c);
     if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
     HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(Status) * STATUS_SLOTS, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->base = Status{};
     c->polys_in = 0;
     return LT_OK;
@@ -470,9 +589,9 @@ int lt_set_profiling(lt_ctx *c, int on)
     if (!c) return LT_ERR_ARG;
     int rc = use_device(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = sync_all(c))) return rc;
     if ((rc = collect(c))) return rc;
-    c->profiling = on != 0;
+    c->profiling = on == 1 ? (1 << LT_STAGES) - 1 : (on & ((1 << LT_STAGES) - 1));
     return LT_OK;
 }
 
@@ -493,7 +612,7 @@ int lt_texture_upload(lt_ctx *c, int handle, const int32_t *texels, int log_size
     if (log_size < 0 || log_size > 12) return fail(c, LT_ERR_ARG, "texture log size %d outside 0..12", log_size);
     int rc = use_device(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = sync_all(c))) return rc;
     if (c->tex_data[handle]) { HIPCHK(c, hipFree(c->tex_data[handle])); c->tex_data[handle] = nullptr; }
     size_t bytes = sizeof(int) << (2 * log_size);
     HIPCHK(c, hipMalloc((void **)&c->tex_data[handle], bytes));
@@ -528,9 +647,6 @@ int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts,
     if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_submit_object: log_focus %d outside 0..30", log_focus);
     if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
     if ((rc = use_device(c))) return rc;
-    // the transform is applied inside the setup kernel: its stage time is part of "setup"
-    if ((rc = mark(c))) return rc;
-    if ((rc = mark(c))) return rc;
     return run_batch(c, false, dim, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts, npv, render_type,
                      log_focus, force_linear, max_edges);
 }
@@ -545,6 +661,7 @@ int lt_submit_object(lt_ctx *c, const int32_t m[12], const int32_t *verts, int n
         return fail(c, LT_ERR_ARG, "lt_submit_object: bad argument");
     int rc = use_device(c);
     if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
     if ((rc = ensure(c, c->s_verts, (size_t)nv * 16))) return rc;
     if ((rc = ensure(c, c->s_polys, (size_t)np * 16))) return rc;
     if ((rc = ensure(c, c->s_pv, (size_t)npv * 24))) return rc;
@@ -570,6 +687,7 @@ int lt_submit_screen_polys(lt_ctx *c, int kind, const int32_t *tuples, int ntupl
     if (n < 0 || ntuples <= 0 || !tuples || !desc) return fail(c, LT_ERR_ARG, "lt_submit_screen_polys: bad argument");
     if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
     if ((rc = use_device(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
     if ((rc = ensure(c, c->s_polys, (size_t)n * 16))) return rc;
     if ((rc = ensure(c, c->s_pv, (size_t)ntuples * dim * 4))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->s_polys.p, desc, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));

@@ -72,7 +72,8 @@ struct SetupArgs {
     unsigned *queue;         // polygons left to the general kernel by the fast one (null: general kernel takes all)
     unsigned *queue_count;   // QUEUES counters, QUEUE_COUNT_STRIDE words apart
     unsigned queue_cap;      // entries per sub-queue
-    int *order_flag;         // device word raised when a textured polygon's vertex lights differ
+    int *order_flag;         // device word set to order_gen when a textured polygon's vertex lights differ
+    int order_gen;           // this batch's number (never 0): a stale flag of an earlier batch does not count
     int detect_order;
     int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
     int band_y0, band_y1;    // rows [band_y0, band_y1) are drawn by this context (whole screen: 0, H)
@@ -93,7 +94,8 @@ struct RasterArgs {
     int clear_pending, clear_colour;
     const int *prp;
     int log_focus;
-    const int *order_flag;   // see ordered_kernel
+    const int *order_flag;   // see ordered_kernel: raised for this batch iff *order_flag == order_gen
+    int order_gen, force_order;
     const int *const *tex_ptr;     // device table of texture base pointers
     const int *tex_log;            // device table of log sizes
     int band_y0, band_y1;          // rows drawn by this context
@@ -105,7 +107,7 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
 // tile lists: count -> exclusive scan -> scatter (count must be zero before the call)
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    Status *status, hipEvent_t after_scan);
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan);
 void launch_raster(hipStream_t s, int na, const RasterArgs &a);
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a);   // textured batches only
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);

@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
     if (dm && (threadIdx.x & 63) == (__ffsll((long long)dm) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(dm));
     if (DIM == 8 && a.detect_order) {
         const unsigned long long om = __ballot(drawn && vary);
-        if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = 1;
+        if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = a.order_gen;
     }
 }
 
@@ -764,7 +764,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     if (DIM == 8 && a.detect_order) {
         const bool ord = draw && lights_vary && kind >= KIND_TEX_LIN;
         const unsigned long long om = __ballot(ord);
-        if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = 1;
+        if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = a.order_gen;
     }
 
     // counters: one atomic per wave, spread over the status slots
@@ -888,10 +888,13 @@ __global__ void __launch_bounds__(256) scatter_direct_kernel(const PrimHdr *__re
 }
 
 // Exclusive prefix sum of the per-tile reference counts (one workgroup; the tile count
-// is at most a few hundred thousand).  Also zeroes the scatter cursors.
-__global__ void __launch_bounds__(1024) scan_kernel(const unsigned *__restrict__ count, unsigned *__restrict__ offset,
+// is at most a few hundred thousand).  Also zeroes the scatter cursors, and leaves the
+// counts and the set-up sub-queue counters at zero for the next batch that uses these
+// arrays (they are zero when allocated), so no batch needs a memset.
+__global__ void __launch_bounds__(1024) scan_kernel(unsigned *__restrict__ count, unsigned *__restrict__ offset,
                                                     unsigned *__restrict__ cursor, int n,
-                                                    unsigned long long capacity, Status *status)
+                                                    unsigned long long capacity, unsigned *__restrict__ queue_count,
+                                                    Status *status)
 {
     __shared__ unsigned wsum[16];
     __shared__ unsigned carry_s;
@@ -901,6 +904,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(const unsigned *__restrict__
     for (int base = 0; base < n; base += 1024) {
         int i = base + t;
         unsigned v = i < n ? count[i] : 0u;
+        if (i < n) count[i] = 0u;
         unsigned s = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -917,6 +921,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(const unsigned *__restrict__
         if (t == 1023) carry_s = carry + pre + s;
         __syncthreads();
     }
+    if (queue_count && t < QUEUES) queue_count[t * QUEUE_COUNT_STRIDE] = 0u;
     if (t == 0) {
         offset[n] = carry_s;
         atomicAdd(&status->tile_refs, (unsigned long long)carry_s);
@@ -1148,7 +1153,7 @@ template <int NA>
 __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
 {
     extern __shared__ int band_lds[];
-    if (!*a.order_flag) return;
+    if (!(a.force_order || *a.order_flag == a.order_gen)) return;
     const int W = a.W;
     int *zt = band_lds, *ct = band_lds + R * W;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1251,7 +1256,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         lcnt = a.list_capacity > lbeg ? (unsigned)(a.list_capacity - lbeg) : 0u;
     if (lcnt == 0 && !a.clear_pending) return;       // untouched tile of a frame that is already in HBM
     if (ty0 + TH <= a.band_y0 || ty0 >= a.band_y1) return;      // outside the band this context draws
-    if (NA == 6 && *a.order_flag) return;            // the draw-order kernel fills this batch
+    if (NA == 6 && (a.force_order || *a.order_flag == a.order_gen)) return;      // the draw-order kernel fills this batch
 
     // ---- tile in: depth only
     for (int p = t; p < TW * TH; p += RASTER_THREADS) {
@@ -1544,14 +1549,14 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
 
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    Status *status, hipEvent_t after_scan)
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan)
 {
     const bool lds = ntiles <= BIN_MAX_TILES;
     if (np > 0) {
         if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, tiles_x, ntiles, count);
         else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, tiles_x, count);
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, (const unsigned *)count, offset, cursor, ntiles, capacity, status);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, cursor, ntiles, capacity, queue_count, status);
     if (after_scan) (void)hipEventRecord(after_scan, s);
     if (np > 0) {
         if (lds) hipLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity);

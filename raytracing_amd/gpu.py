@@ -89,6 +89,10 @@ class Context:
         self._chk(self.L.lt_bind_framebuffer(self.h_ctx, _dp(d_colour), _dp(d_depth)))
         self._bound = (d_colour, d_depth)          # keep the tensors alive while bound
 
+    def set_pipelining(self, on):
+        """overlap a batch's set-up with the fill of the batch before it (default on)"""
+        self._chk(self.L.lt_set_pipelining(self.h_ctx, int(on)))
+
     def set_band(self, y0, y1):
         """this context draws only rows [y0, y1) of the screen"""
         self._chk(self.L.lt_set_band(self.h_ctx, y0, y1))
@@ -105,7 +109,17 @@ class Context:
         """0 auto, 1 always the draw-order kernel for textured batches, 2 never"""
         self._chk(self.L.lt_set_textured_order(self.h_ctx, mode))
 
+    STAGES = ("transform", "setup", "scan", "bin", "fill")
+
     def set_profiling(self, on):
+        """True/False, or a stage name / list of stage names to time only those"""
+        if isinstance(on, str):
+            on = [on]
+        if isinstance(on, (list, tuple)):
+            mask = 0
+            for name in on:
+                mask |= 1 << self.STAGES.index(name)
+            on = mask if mask != 1 else 1
         self._chk(self.L.lt_set_profiling(self.h_ctx, int(on)))
 
     def stage_ms(self):

@@ -1,0 +1,88 @@
+"""Batches in flight: set-up of a batch overlaps the fill of the batch before it (two
+streams, two sets of work arrays).  Draw order across batches and the result of every
+frame must not depend on that."""
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import oracle.port as P
+    from raytracing_amd import gpu as G
+    return P, G
+
+
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_many_batches_one_frame(env, pipelined):
+    """seven batches of different sizes drawn over each other from device arrays, no flush
+    in between: the third batch reuses the work arrays of the first, and so on"""
+    import torch
+    P, G = env
+    W, H = 640, 480
+    ctx = G.Context(W, H)
+    ctx.set_pipelining(pipelined)
+    orc = P.Oracle(W, H)
+    orc.clear(0x101010, 255, 255, 255)
+    ctx.clear(P.cl_light(0x101010, 255, 255, 255))
+    keep = []
+    for b, n in enumerate([5000, 300, 12000, 1, 7000, 2500, 9000]):
+        sc = S.gen_c2(n, W, H, 9, radius=10 + 6 * b, seed=1000 + b)
+        orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, None, sc.polyverts, sc.render_type, sc.log_focus)
+        d = [torch.from_numpy(a).cuda() for a in (sc.verts, sc.polys, sc.polyverts)]
+        keep.append(d)                                  # inputs stay valid until the flush
+        ctx.submit_object_dev(d[0], d[1], d[2], sc.render_type, sc.log_focus, matrix=sc.matrix, max_edges=3)
+    c, z = ctx.readback()
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert ctx.counters()["fragments"] == orc.counters()["fragments"]
+
+
+def test_frames_back_to_back_match_frames_one_by_one(env):
+    """clear + draw, six different frames without a flush; every second frame is read back
+    through a bound frame of its own, the last one from the context"""
+    import torch
+    P, G = env
+    W, H = 640, 480
+    scenes = [S.gen_c2(6000 + 500 * f, W, H, 9, radius=12, seed=2000 + f) for f in range(6)]
+    ctx = G.Context(W, H)
+    dev = [[torch.from_numpy(a).cuda() for a in (sc.verts, sc.polys, sc.polyverts)] for sc in scenes]
+    for f, (sc, d) in enumerate(zip(scenes, dev)):
+        ctx.clear(f * 0x010101)
+        ctx.submit_object_dev(d[0], d[1], d[2], sc.render_type, sc.log_focus, matrix=sc.matrix, max_edges=3)
+    c, z = ctx.readback()
+    orc = P.Oracle(W, H)
+    orc.clear(5 * 0x010101, 255, 255, 255)
+    sc = scenes[5]
+    orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, None, sc.polyverts, sc.render_type, sc.log_focus)
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+
+
+def test_caller_stream_produces_inputs(env):
+    """the vertex array is produced by lt_transform on the caller's stream right before the
+    submit that reads it: the batch waits for it"""
+    import torch
+    P, G = env
+    W, H = 640, 480
+    sc = S.gen_c2(8000, W, H, 9, radius=14, seed=31)
+    from raytracing_amd.transform import make_matrix
+    m = make_matrix((0, 0, 0, 0, 0, 0), (3, 250, 7, 5, -4, 6))
+    ctx = G.Context(W, H)
+    stream = torch.cuda.Stream()
+    ctx.set_stream(stream.cuda_stream)
+    d_obj = torch.from_numpy(sc.verts).cuda()
+    d_polys = torch.from_numpy(sc.polys).cuda()
+    d_pv = torch.from_numpy(sc.polyverts).cuda()
+    d_view = torch.zeros((sc.verts.shape[0], 4), dtype=torch.int32, device="cuda")   # rows of 4: x, y, z, pad
+    torch.cuda.synchronize()
+    ctx.clear(0)
+    ctx.transform(m, d_obj, d_view)
+    ctx.submit_object_dev(d_view, d_polys, d_pv, sc.render_type, sc.log_focus, matrix=None, max_edges=3)
+    c, z = ctx.readback()
+    orc = P.Oracle(W, H)
+    orc.clear(0, 0, 0, 0)
+    orc.render_polys(P.transform(m, sc.verts), sc.polys, None, sc.polyverts, sc.render_type, sc.log_focus)
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    ctx.close()
