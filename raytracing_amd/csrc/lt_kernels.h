@@ -24,8 +24,9 @@ struct PrimHdr { int yy, xx, colour, meta; };
 //   {x1|y1<<16, x2|y2<<16, Zstart, Zinc, start[1..NA-1], inc[1..NA-1], padding}
 // Zstart = Z1<<16, Zinc = ((Z2-Z1)<<16)/L; the other values as in GraphicsPoly.cpp:171-176.
 // NA = 1 (flat: 4 ints), 4 (shaded: 12 ints), 6 (textured: 16 ints).  The depth pass
-// reads only the first piece.  Edge k of polygon p lives at edges[(k*np + p)*ESZ]: a
-// wave of the setup kernel writes consecutive records, and no allocation is needed.
+// reads only the first piece.  The pool is laid out [edge][piece][polygon] in 16-byte
+// units: piece q of edge k of polygon p is unit (k*(ESZ/4) + q)*np + p, so the lanes of a
+// setup wave (consecutive polygons) store adjacent pieces, and no allocation is needed.
 __host__ __device__ constexpr int edge_ints(int na) { return na == 1 ? 4 : (na == 4 ? 12 : 16); }
 
 // Constants of G_prp_textured_polygon for one polygon (GraphicsPoly.cpp:563-578):

@@ -264,6 +264,17 @@ __device__ bool tmapping_vectors(int type, const Tup<8> &p1, const Tup<8> &p2, c
 
 constexpr int KIND_FLAT = 2, KIND_SHADED = 4, KIND_TEX_LIN = 8, KIND_TEX_PRP = 9;
 
+// 16-byte piece `piece` of the record of edge `e` of polygon `poly`: the pool is laid out
+// [edge][piece][polygon], `np` polygons.
+__device__ __forceinline__ int4 *edge_piece(int *edges, int np, int npieces, int e, int piece, int poly)
+{
+    return (int4 *)edges + ((size_t)(e * npieces + piece) * np + poly);
+}
+__device__ __forceinline__ const int4 *edge_piece(const int *edges, int np, int npieces, int e, int piece, int poly)
+{
+    return (const int4 *)edges + ((size_t)(e * npieces + piece) * np + poly);
+}
+
 // Edge record of one scanned edge v1 -> v2 (after the y clip): GI_scan's set-up,
 // GraphicsPoly.cpp:147-176.  record = {x1|y1<<16, x2|y2<<16, Zstart, Zinc, other starts..,
 // other incs..} in 16-byte pieces; edge `slot` of every polygon lies in plane `slot`.
@@ -291,9 +302,11 @@ __device__ __forceinline__ void store_edge_record(const SetupArgs &a, int poly, 
         rec[3 + q] = v1.v[2 + q];
         rec[3 + (NA - 1) + q] = L > 0 ? tdivr(wsub(v2.v[2 + q], v1.v[2 + q]), rL) : 0;
     }
-    int4 *r = (int4 *)(a.edges + ((size_t)slot * a.np + poly) * ESZ);
+    // piece q of edge `slot` of all polygons is one array: consecutive lanes (polygons)
+    // store adjacent 16-byte pieces
 #pragma unroll
-    for (int q = 0; q < ESZ / 4; q++) r[q] = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+    for (int q = 0; q < ESZ / 4; q++)
+        *edge_piece(a.edges, a.np, ESZ / 4, slot, q, poly) = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
 }
 
 // Triangles that need no clipping at all take this kernel: volume test passed with every
@@ -999,14 +1012,20 @@ __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, 
         first = 3;
     }
     for (int e = first; e < ne; e++) {
-        const int2 xy = *(const int2 *)(edges + ((size_t)e * np + poly) * ESZ);
+        const int2 xy = *(const int2 *)edge_piece(edges, np, ESZ / 4, e, 0, poly);
         int ia, xa, ib, xb;
         if (!edge_row(xy.x, xy.y, y, ia, xa, ib, xb)) continue;
         if (xa < bx) { bx = xa; be = e; bi = ia; }
         if (ex < xb) { ex = xb; ee = e; ei = ib; }
     }
     if (bx == INT_MAX) return false;
-    const int *rb = edges + ((size_t)be * np + poly) * ESZ, *re = edges + ((size_t)ee * np + poly) * ESZ;
+    int rb[ESZ], re[ESZ];
+#pragma unroll
+    for (int q = 0; q < ESZ / 4; q++) {
+        const int4 vb = *edge_piece(edges, np, ESZ / 4, be, q, poly), ve = *edge_piece(edges, np, ESZ / 4, ee, q, poly);
+        rb[4 * q] = vb.x; rb[4 * q + 1] = vb.y; rb[4 * q + 2] = vb.z; rb[4 * q + 3] = vb.w;
+        re[4 * q] = ve.x; re[4 * q + 1] = ve.y; re[4 * q + 2] = ve.z; re[4 * q + 3] = ve.w;
+    }
     S[0] = wadd(rb[2], wmul(bi, rb[3]));
     E[0] = wadd(re[2], wmul(ei, re[3]));
 #pragma unroll
@@ -1055,12 +1074,12 @@ __device__ __forceinline__ bool depth_row3(const Edge4 (&ed)[3], int ne, int y, 
     return true;
 }
 
-__device__ __forceinline__ bool depth_row_mem(const int *__restrict__ edges, int esz, int np, int poly, int ne, int y,
+__device__ __forceinline__ bool depth_row_mem(const int *__restrict__ edges, int npieces, int np, int poly, int ne, int y,
                                               int &beg, int &end, int &zs, int &zi)
 {
     int bx = INT_MAX, ex = INT_MIN, sz = 0, ez = 0;
     for (int e = 0; e < ne; e++) {
-        const int4 r = *(const int4 *)(edges + ((size_t)e * np + poly) * esz);
+        const int4 r = *edge_piece(edges, np, npieces, e, 0, poly);
         int ia, xa, ib, xb;
         if (!edge_row(r.x, r.y, y, ia, xa, ib, xb)) continue;
         if (xa < bx) { bx = xa; sz = wadd(r.z, wmul(ia, r.w)); }
@@ -1283,17 +1302,17 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     int4 h_c = zero4, e0_c = zero4, e1_c = zero4, e2_c = zero4;
     if (poly_c >= 0) {
         h_c = ((const int4 *)a.hdr)[poly_c];
-        e0_c = *(const int4 *)(a.edges + ((size_t)0 * a.np + poly_c) * ESZ);
-        e1_c = *(const int4 *)(a.edges + ((size_t)1 * a.np + poly_c) * ESZ);
-        e2_c = *(const int4 *)(a.edges + ((size_t)2 * a.np + poly_c) * ESZ);
+        e0_c = *edge_piece(a.edges, a.np, ESZ / 4, 0, 0, poly_c);
+        e1_c = *edge_piece(a.edges, a.np, ESZ / 4, 1, 0, poly_c);
+        e2_c = *edge_piece(a.edges, a.np, ESZ / 4, 2, 0, poly_c);
     }
     for (unsigned rd = 0; rd < rounds; rd++) {
         int4 h_n = zero4, e0_n = zero4, e1_n = zero4, e2_n = zero4;
         if (poly_n >= 0) {
             h_n = ((const int4 *)a.hdr)[poly_n];
-            e0_n = *(const int4 *)(a.edges + ((size_t)0 * a.np + poly_n) * ESZ);
-            e1_n = *(const int4 *)(a.edges + ((size_t)1 * a.np + poly_n) * ESZ);
-            e2_n = *(const int4 *)(a.edges + ((size_t)2 * a.np + poly_n) * ESZ);
+            e0_n = *edge_piece(a.edges, a.np, ESZ / 4, 0, 0, poly_n);
+            e1_n = *edge_piece(a.edges, a.np, ESZ / 4, 1, 0, poly_n);
+            e2_n = *edge_piece(a.edges, a.np, ESZ / 4, 2, 0, poly_n);
         }
         const unsigned li2 = (rd + 2) * RASTER_THREADS + slot;
         const int poly_nn = li2 < lcnt ? (int)a.tile_list[lbeg + li2] : -1;
@@ -1361,7 +1380,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                         }
                         ok = depth_row3(oe, one, y, beg, end, zs, zi);
                     } else {
-                        ok = depth_row_mem(a.edges, ESZ, a.np, opoly, one, y, beg, end, zs, zi);
+                        ok = depth_row_mem(a.edges, ESZ / 4, a.np, opoly, one, y, beg, end, zs, zi);
                     }
                     if (ok) {
                         const int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
@@ -1403,7 +1422,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                 bool ok = false;
                 if (y < br1)
                     ok = bne <= 3 ? depth_row3(be, bne, y, beg, end, zs, zi)
-                                  : depth_row_mem(a.edges, ESZ, a.np, bpoly, bne, y, beg, end, zs, zi);
+                                  : depth_row_mem(a.edges, ESZ / 4, a.np, bpoly, bne, y, beg, end, zs, zi);
                 if (!ok) { beg = 0; end = -1; }
             }
             // depth at this lane's pixel column if the span started there: z = zc + x*zi
@@ -1447,7 +1466,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                 hh[g] = ((const int4 *)a.hdr)[poly];
                 if (NA > 1) {
 #pragma unroll
-                    for (int e = 0; e < 3; e++) xy[g][e] = *(const int2 *)(a.edges + ((size_t)e * a.np + poly) * ESZ);
+                    for (int e = 0; e < 3; e++) xy[g][e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
                 }
             }
         }
