@@ -42,7 +42,7 @@ def make_scene(workload, tris):
     if workload == "c2-large":
         return S.gen_c2(tris, 1920, 1080, 10, radius=128)
     if workload == "c3-lin":
-        return S.gen_c3(tris, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=100)
+        return S.gen_c3(tris, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=100, regular_mapping=True)
     if workload == "c5":
         return S.gen_c2(tris, 16384, 16384, 13, radius=16, seed=0xC0FFEE05)
     raise SystemExit(f"unknown workload {workload}")

@@ -229,7 +229,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if ((rc = ensure(c, w.tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
     if ((rc = ensure_zeroed(c, w.scratch, kScratchBytes))) return rc;
     const unsigned qcap = setup_queue_cap(np);
-    if (!screen && (rc = ensure(c, w.queue, (size_t)qcap * QUEUES * sizeof(unsigned)))) return rc;
+    if (!screen && (rc = ensure(c, w.queue, (size_t)qcap * QUEUES * sizeof(uint2)))) return rc;
     int *order_flag = (int *)w.scratch.p;
 
     // the transform is applied inside the setup kernel: its stage is empty
@@ -253,7 +253,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.prp = want_prp ? (int *)w.prp.p : nullptr;
     sa.order_flag = order_flag; sa.order_gen = order_gen; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
     // object batches: unclipped triangles take the fast kernel, the rest go through sub-queues
-    sa.queue = screen ? nullptr : (unsigned *)w.queue.p;
+    sa.queue = screen ? nullptr : (uint2 *)w.queue.p;
     sa.queue_count = (unsigned *)(order_flag + 64);      // behind the order flag in the small device scratch
     sa.queue_cap = qcap;
     sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;

@@ -70,7 +70,7 @@ struct SetupArgs {
     int emax;                // edge slots per polygon
     PrimHdr *hdr;
     int *edges;
-    unsigned *queue;         // polygons left to the general kernel by the fast one (null: general kernel takes all)
+    uint2 *queue;            // {polygon, output slot} left to the general kernel by the fast one (null: it takes all, slot = polygon)
     unsigned *queue_count;   // QUEUES counters, QUEUE_COUNT_STRIDE words apart
     unsigned queue_cap;      // entries per sub-queue
     int *order_flag;         // device word set to order_gen when a textured polygon's vertex lights differ

@@ -11,6 +11,7 @@
 // of the order in which lanes, waves and workgroups happen to run.
 #include "lt_kernels.h"
 #include <limits.h>
+#include <algorithm>
 
 namespace lt {
 
@@ -116,11 +117,13 @@ __global__ void __launch_bounds__(256) transform_kernel(Mat12 M, const int4 *__r
     d[2] = o[2];
 }
 
+// lane `l` of v, l wave-uniform
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
 // The same transform applied to one vertex as the setup kernel reads it, so that an
 // object's view-space vertices never make a round trip through HBM.
-__device__ __forceinline__ int4 load_vertex(const SetupArgs &a, int idx)
+__device__ __forceinline__ int4 view_vertex(const SetupArgs &a, int4 p)
 {
-    int4 p = ((const int4 *)a.verts)[idx];
     if (a.use_matrix) {
         int o[3];
 #pragma unroll
@@ -131,6 +134,11 @@ __device__ __forceinline__ int4 load_vertex(const SetupArgs &a, int idx)
         p.x = o[0]; p.y = o[1]; p.z = o[2];
     }
     return p;
+}
+
+__device__ __forceinline__ int4 load_vertex(const SetupArgs &a, int idx)
+{
+    return view_vertex(a, ((const int4 *)a.verts)[idx]);
 }
 
 // ------------------------------------------------------------------ clipping
@@ -318,24 +326,54 @@ __device__ __forceinline__ void store_edge_record(const SetupArgs &a, int poly, 
 // screen-border contact, perspective-mapped textures) is appended to a queue for the
 // general kernel, which then runs only on those polygons with all its lanes busy.
 template <int DIM>
-__global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
+__global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArgs a)
 {
     constexpr int NA = DIM - 2;
+    __shared__ int4 stage_f[SETUP_FAST_THREADS / 64][6 * 64];     // per wave: 64 x 4 vertex records of 24 bytes
     const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int4 *stg = stage_f[threadIdx.x >> 6];
     const bool inrange = poly < a.np;
-    bool slow = false, drawn = false, vary = false;
-    int4 hdr = make_int4(0, 0, 0, 0);
+    const bool wave_full = __ballot(inrange) == ~0ull;
+    bool slow = false, drawn = false, vary = false, offscreen = false, visible = false;
+    Tup<DIM> t[4];
+    int colour = 0, tex = 0, kind = a.render_type, by0 = 0, by1 = 0, minx = 0, maxx = 0;
     if (inrange) {
         const int4 pd = ((const int4 *)a.polys)[poly];
-        const int colour = pd.x, tex = pd.y, e = pd.z, first = pd.w;
-        int kind = a.render_type;
+        colour = pd.x; tex = pd.y;
+        const int e = pd.z, first = pd.w;
         if (kind == KIND_TEX_LIN && tex < 0) kind = KIND_SHADED;
         if (e != 3 || e > a.max_edges || first < 0 || (long long)first + 4 > (long long)a.npv ||
             (kind == KIND_TEX_LIN && tex >= 64))
             slow = true;
-        Tup<DIM> t[4];
-        if (!slow) {
-            int2 ra[4], rb[4], rc[4];
+        int2 ra[4] = {}, rb[4] = {}, rc[4] = {};
+        // A wave whose 64 triangles keep their vertex records one after the other
+        // (first = first0 + 4*lane) reads the 6 KB block with consecutive 16-byte loads
+        // and hands each lane its 96 bytes through LDS: a lane-per-record gather would
+        // touch 64 different cache lines per load instruction.
+        const int first0 = rdlane(first, 0);
+        const bool rec_seq = wave_full && __ballot(!slow && first == first0 + 4 * lane) == ~0ull && (first0 & 1) == 0 &&
+                             (long long)first0 + 256 <= (long long)a.npv;
+        if (rec_seq) {
+            const int4 *blk = (const int4 *)(a.polyverts + (size_t)first0 * 6);
+#pragma unroll
+            for (int k = 0; k < 6; k++) stg[k * 64 + lane] = blk[k * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int r[24];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int4 q = stg[lane * 6 + k];
+                r[4 * k] = q.x; r[4 * k + 1] = q.y; r[4 * k + 2] = q.z; r[4 * k + 3] = q.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ra[i] = make_int2(r[6 * i], r[6 * i + 1]);
+                rb[i] = make_int2(r[6 * i + 2], r[6 * i + 3]);
+                rc[i] = make_int2(r[6 * i + 4], r[6 * i + 5]);
+            }
+        } else if (!slow) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int2 *rec = (const int2 *)(a.polyverts + (size_t)(first + i) * 6);
@@ -343,20 +381,42 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
                 rb[i] = DIM >= 6 ? rec[1] : make_int2(0, 0);
                 rc[i] = DIM == 8 ? rec[2] : make_int2(0, 0);
             }
+        }
+        if (!slow) {
 #pragma unroll
             for (int i = 0; i < 4; i++)
                 if ((unsigned)ra[i].x >= (unsigned)a.nv) slow = true;
-            if (!slow) {
+        }
+        // likewise the vertices of a triangle soup: indices v0 + 3*lane + {0, 1, 2, 0}
+        const int v0 = rdlane(ra[0].x, 0);
+        const bool vert_seq = wave_full && (long long)v0 + 192 <= (long long)a.nv && v0 >= 0 &&
+                              __ballot(!slow && ra[0].x == v0 + 3 * lane && ra[1].x == ra[0].x + 1 &&
+                                       ra[2].x == ra[0].x + 2 && ra[3].x == ra[0].x) == ~0ull;
+        int4 pv[4];
+        if (vert_seq) {
+            const int4 *blk = (const int4 *)a.verts + v0;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int4 p = load_vertex(a, ra[i].x);
-                    t[i].v[0] = p.x; t[i].v[1] = p.y; t[i].v[2] = p.z;
-                    if (DIM >= 6) { t[i].v[3] = wshl(ra[i].y, 16); t[i].v[4] = wshl(rb[i].x, 16); t[i].v[5] = wshl(rb[i].y, 16); }
-                    if (DIM == 8) {
-                        const bool tx = kind == KIND_TEX_LIN;
-                        t[i].v[DIM - 2] = tx ? wshl(rc[i].x, 16) : 0;
-                        t[i].v[DIM - 1] = tx ? wshl(rc[i].y, 16) : 0;
-                    }
+            for (int k = 0; k < 3; k++) stg[k * 64 + lane] = blk[k * 64 + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 3; i++) pv[i] = stg[lane * 3 + i];
+            pv[3] = pv[0];
+            __builtin_amdgcn_wave_barrier();
+        } else if (!slow) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) pv[i] = ((const int4 *)a.verts)[ra[i].x];
+        }
+        if (!slow) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int4 p = view_vertex(a, pv[i]);
+                t[i].v[0] = p.x; t[i].v[1] = p.y; t[i].v[2] = p.z;
+                if (DIM >= 6) { t[i].v[3] = wshl(ra[i].y, 16); t[i].v[4] = wshl(rb[i].x, 16); t[i].v[5] = wshl(rb[i].y, 16); }
+                if (DIM == 8) {
+                    const bool tx = kind == KIND_TEX_LIN;
+                    t[i].v[DIM - 2] = tx ? wshl(rc[i].x, 16) : 0;
+                    t[i].v[DIM - 1] = tx ? wshl(rc[i].y, 16) : 0;
                 }
             }
         }
@@ -380,7 +440,7 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
                        t[3].v[3] != t[0].v[3] || t[3].v[4] != t[0].v[4] || t[3].v[5] != t[0].v[5];
             // T_perspective, TransBs.cpp:425-432
             const int xc = a.W / 2, yc = a.H / 2;
-            bool inside = true;
+            bool inside = true, left = true, right = true, above = true, below = true;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int z = t[i].v[2];
@@ -389,8 +449,18 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
                 t[i].v[1] = wadd(persp_div(t[i].v[1], a.log_focus, z, rz), yc);
                 t[i].v[2] = tdivr(-0x7ffff, rz);
                 inside = inside && t[i].v[0] > 0 && t[i].v[0] < a.W - 1 && t[i].v[1] > 0 && t[i].v[1] < a.H - 1;
+                left = left && t[i].v[0] <= 0;
+                right = right && t[i].v[0] >= a.W - 1;
+                above = above && t[i].v[1] <= 0;
+                below = below && t[i].v[1] >= a.H - 1;
             }
-            if (!inside) { slow = true; go = false; }
+            // Wholly on the outer side of one screen border: the x clipper drops every
+            // edge whose two ends are at or beyond the same bound (Clipp2D.cpp:115-118),
+            // and so does the y clipper of the scan (:188-191) -- clipped points lie
+            // between their edge's ends -- so nothing is drawn; the polygon still counts
+            // as drawn if it faces the viewer, as in M_render_polygon.
+            offscreen = left || right || above || below;
+            if (!inside && !offscreen) { slow = true; go = false; }
         }
         if (go) {
             // T_normal_z_negative, TransLn.cpp:218-223
@@ -401,41 +471,54 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
         if (go) {
             drawn = true;
             const int miny = min(t[1].v[1], min(t[2].v[1], t[3].v[1])), maxy = max(t[1].v[1], max(t[2].v[1], t[3].v[1]));
-            const int minx = min(t[1].v[0], min(t[2].v[0], t[3].v[0])), maxx = max(t[1].v[0], max(t[2].v[0], t[3].v[0]));
+            minx = min(t[1].v[0], min(t[2].v[0], t[3].v[0]));
+            maxx = max(t[1].v[0], max(t[2].v[0], t[3].v[0]));
             // rows outside the band of this context are another context's to draw
-            const int by0 = max(miny, a.band_y0), by1 = min(maxy, a.band_y1);
-            if (by0 < by1) {
-                store_edge_record<DIM>(a, poly, 0, t[1], t[2]);
-                store_edge_record<DIM>(a, poly, 1, t[2], t[3]);
-                store_edge_record<DIM>(a, poly, 2, t[3], t[1]);
-                int col = colour;
-                if (kind == KIND_FLAT) {
-                    const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
-                    col = cl_light(colour, ax.x, ax.y, ax.z);
-                }
-                hdr = make_int4(by0 | (by1 << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
-            }
+            by0 = max(miny, a.band_y0);
+            by1 = min(maxy, a.band_y1);
+            visible = by0 < by1 && !offscreen;
         }
-        if (!slow) ((int4 *)a.hdr)[poly] = hdr;
     }
-    // queue the rest for the general kernel: one atomic per wave, spread over QUEUES
-    // sub-queues by workgroup index (thousands of waves adding to one word would queue
-    // behind each other); sub-queue q holds at most `queue_cap` entries by construction
+    // Output slots.  About half of a soup's triangles face away, and writing records with
+    // holes between them costs more HBM time than writing twice as many without (partial
+    // lines): the polygons of this wave that go on -- visible here, or left to the general
+    // kernel -- take the slots base .. base+count-1 of the wave's 64 in lane order, and the
+    // rest of the 64 headers is zeroed.  Slot order is polygon order, and everything after
+    // set-up (binning, fill, draw-order ties) knows a polygon by its slot.
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long keep = __ballot(visible || slow);
+    const int base = poly & ~63, count = __popcll(keep);
+    const int slot = base + __popcll(keep & below);
+    if (visible) {
+        store_edge_record<DIM>(a, slot, 0, t[1], t[2]);
+        store_edge_record<DIM>(a, slot, 1, t[2], t[3]);
+        store_edge_record<DIM>(a, slot, 2, t[3], t[1]);
+        int col = colour;
+        if (kind == KIND_FLAT) {
+            const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
+            col = cl_light(colour, ax.x, ax.y, ax.z);
+        }
+        ((int4 *)a.hdr)[slot] = make_int4(by0 | (by1 << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
+    }
+    if (lane >= count && base + lane < a.np) ((int4 *)a.hdr)[base + lane] = make_int4(0, 0, 0, 0);
+    // queue the rest for the general kernel as {polygon, slot}: one atomic per wave,
+    // spread over QUEUES sub-queues by workgroup index (thousands of waves adding to one
+    // word would queue behind each other); sub-queue q holds at most `queue_cap` entries
+    // by construction
     const unsigned long long sm = __ballot(slow);
     if (sm) {
-        const int lane = threadIdx.x & 63;
         const int leader = __ffsll((long long)sm) - 1;
         const int q = blockIdx.x % QUEUES;
-        unsigned base = 0;
-        if (lane == leader) base = atomicAdd(a.queue_count + q * QUEUE_COUNT_STRIDE, (unsigned)__popcll(sm));
-        base = __shfl(base, leader);
-        if (slow) a.queue[(size_t)q * a.queue_cap + base + __popcll(sm & ((1ull << lane) - 1ull))] = (unsigned)poly;
+        unsigned qbase = 0;
+        if (lane == leader) qbase = atomicAdd(a.queue_count + q * QUEUE_COUNT_STRIDE, (unsigned)__popcll(sm));
+        qbase = __shfl(qbase, leader);
+        if (slow) a.queue[(size_t)q * a.queue_cap + qbase + __popcll(sm & below)] = make_uint2((unsigned)poly, (unsigned)slot);
     }
     Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
     const unsigned long long dm = __ballot(drawn);
     if (dm && (threadIdx.x & 63) == (__ffsll((long long)dm) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(dm));
     if (DIM == 8 && a.detect_order) {
-        const unsigned long long om = __ballot(drawn && vary);
+        const unsigned long long om = __ballot(drawn && vary && !offscreen);
         if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = a.order_gen;
     }
 }
@@ -459,17 +542,10 @@ __global__ void __launch_bounds__(256) setup_fast_kernel(SetupArgs a)
 // SCREEN = true starts at the X stage with already-projected tuples (the G_*_polygon
 // entry points); polys[] then holds {first, length, colour, tex} descriptors.
 template <int DIM, bool SCREEN>
-__global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
+__device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, const int slot)
 {
     constexpr int NA = DIM - 2;
     constexpr int ESZ = edge_ints(NA);
-    int poly = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a.queue) {
-        // second stage: only the polygons that the fast kernel passed on (sub-queue blockIdx.y)
-        if ((unsigned)poly >= a.queue_count[blockIdx.y * QUEUE_COUNT_STRIDE]) return;
-        poly = (int)a.queue[(size_t)blockIdx.y * a.queue_cap + poly];
-    } else if (poly >= a.np) return;
-
     PrimHdr hdr;
     hdr.yy = 0; hdr.xx = 0; hdr.colour = 0; hdr.meta = 0;
 
@@ -697,7 +773,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
                     if (clip_line<DIM, 1, true>(sprev, s, 0, hy, v1, v2, moved, bad)) {
                         miny = min(miny, min(v1.v[1], v2.v[1]));
                         maxy = max(maxy, max(v1.v[1], v2.v[1]));
-                        if (ne < a.emax) store_edge_record<DIM>(a, poly, ne, v1, v2);
+                        if (ne < a.emax) store_edge_record<DIM>(a, slot, ne, v1, v2);
                         ne++;
                     }
                 }
@@ -713,6 +789,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     }
 
     bool draw = go && !bad && !unsupported;
+    bool mapper_failed = false;      // faced the viewer, but the perspective mapper cannot be set up
     if (draw && !SCREEN) {
         if (zn < 2) draw = false;
         else {
@@ -730,12 +807,12 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 #pragma unroll
             for (int j = 0; j < 8; j++) { q0.v[j] = org0.v[j % DIM]; q1.v[j] = org1.v[j % DIM]; q2.v[j] = org2.v[j % DIM]; O.v[j] = zfirst_view.v[j % DIM]; }
             if (!a.prp || log_space < 0 || log_space > 24 || !tmapping_vectors(ax.w & 0x0c, q0, q1, q2, log_space, u, v)) {
-                unsupported = true; draw = false;
+                unsupported = true; draw = false; mapper_failed = true;
             } else {
                 kind = KIND_TEX_PRP;
                 // GraphicsPoly.cpp:563-578
                 const int x0 = O.v[0], y0 = O.v[1], z0 = O.v[2];
-                int *pr = a.prp + (size_t)poly * PRP_INTS;
+                int *pr = a.prp + (size_t)slot * PRP_INTS;
                 int4 c0, c1, c2;
                 c0.x = wsub(wmul(v[2], y0), wmul(v[1], z0));      // ui
                 c0.y = wsub(wmul(v[0], z0), wmul(v[2], x0));      // uj
@@ -753,7 +830,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     }
     if (ne > a.emax) { bad = true; draw = false; }
 
-    bool reached_fill = draw;
+    bool reached_fill = draw || mapper_failed;      // M_render_polygon got as far as choosing the fill
     if (draw && !(miny < maxy && ne > 0)) draw = false;
     if (draw) {
         // rows outside the band of this context are another context's to draw
@@ -773,7 +850,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
         hdr.colour = col;
         hdr.meta = ne | (kind << 8) | ((tex < 0 ? 0 : tex) << 16);
     }
-    ((int4 *)a.hdr)[poly] = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
+    ((int4 *)a.hdr)[slot] = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
     if (DIM == 8 && a.detect_order) {
         const bool ord = draw && lights_vary && kind >= KIND_TEX_LIN;
         const unsigned long long om = __ballot(ord);
@@ -789,6 +866,24 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->overflow_polys, (unsigned long long)__popcll(m));
     m = __ballot(unsupported);
     if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->unsupported_polys, (unsigned long long)__popcll(m));
+}
+
+template <int DIM, bool SCREEN>
+__global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
+{
+    if (a.queue) {
+        // second stage: only the polygons that the fast kernel passed on.  Sub-queue
+        // blockIdx.y is shared by the few workgroups of row y of the grid, which stride
+        // through it; its length is only known on the device.
+        const unsigned cnt = a.queue_count[blockIdx.y * QUEUE_COUNT_STRIDE];
+        for (unsigned qi = blockIdx.x * blockDim.x + threadIdx.x; qi < cnt; qi += gridDim.x * blockDim.x) {
+            const uint2 e = a.queue[(size_t)blockIdx.y * a.queue_cap + qi];
+            setup_one<DIM, SCREEN>(a, (int)e.x, (int)e.y);
+        }
+    } else {
+        const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+        if (poly < a.np) setup_one<DIM, SCREEN>(a, poly, poly);
+    }
 }
 
 // ------------------------------------------------------------------ binning
@@ -1037,9 +1132,6 @@ __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, 
     end = ex;
     return true;
 }
-
-// lane `l` of v, l wave-uniform
-__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
 __device__ __forceinline__ unsigned long long depth_key(int z, unsigned id)
 {
@@ -1547,7 +1639,7 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
 {
     if (a.np <= 0) return;
     dim3 g((a.np + SETUP_THREADS - 1) / SETUP_THREADS), b(SETUP_THREADS);
-    if (!screen && a.queue) g = dim3((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, QUEUES);
+    if (!screen && a.queue) g = dim3(std::min((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, 8u), QUEUES);
     if (!screen && a.queue) {
         // fast kernel for unclipped triangles; it queues the rest for the general kernel
         dim3 gf((a.np + 255) / 256), bf(256);

@@ -81,9 +81,32 @@ def make_texture(seed: int, log_size: int) -> np.ndarray:
     return (splitmix64(seed, n) & np.uint64(0x00FFFFFF)).astype(np.int32).reshape(1 << log_size, 1 << log_size)
 
 
+def _regular_texture_mapping(txy: np.ndarray) -> np.ndarray:
+    """Replace the texture coordinates of triangles on which the perspective mapper's
+    2x2 fixed-point elimination (reference T_linear_solve, TransBs.cpp:477-505, reached
+    through MI_tmapping_vectors, EngBase.cpp:163-175) meets a zero pivot -- the reference
+    divides by zero there -- by a fixed well-conditioned triple."""
+    t = txy.astype(np.int64)
+    r0 = t[:, 1] - t[:, 0]                     # rows of the system: (Tx2-Tx1, Ty2-Ty1), (Tx3-Tx2, Ty3-Ty2)
+    r1 = t[:, 2] - t[:, 1]
+    swap = np.abs(r1[:, 0]) > np.abs(r0[:, 0])           # pivot search: first strictly larger magnitude
+    p = np.where(swap[:, None], r1, r0)
+    q = np.where(swap[:, None], r0, r1)
+    p0 = p[:, 0]
+    safe = np.where(p0 == 0, 1, p0)
+    num = p[:, 1] * q[:, 0]
+    quo = np.sign(num) * np.sign(safe) * (np.abs(num) // np.abs(safe))      # C division truncates
+    q11 = q[:, 1] - quo
+    # column 0 all zero: no elimination step, the back substitution then divides by a00 = 0
+    bad = (p0 == 0) | (q11 == 0)
+    out = txy.copy()
+    out[bad] = np.array([[64, 64], [704, 128], [192, 832]], dtype=txy.dtype)
+    return out
+
+
 def _triangles(rng: Rng, n: int, w: int, h: int, lf: int, radius: int, cx_rng, cy_rng, z_rng,
                cull: str, rgb_equal: bool = False, tex: bool = False, first_z_min: int = 0,
-               first_z_frac: int = 0):
+               first_z_frac: int = 0, regular_mapping: bool = False):
     """Common body of the triangle generators: unshared vertices, 4 records per triangle."""
     cx = rng.ints(cx_rng[0], cx_rng[1], n)
     cy = rng.ints(cy_rng[0], cy_rng[1], n)
@@ -127,6 +150,8 @@ def _triangles(rng: Rng, n: int, w: int, h: int, lf: int, radius: int, cx_rng, c
     pv[:, :3, 0] = idx
     pv[:, :3, 1:4] = rgb
     if tex:
+        if regular_mapping:
+            txy = _regular_texture_mapping(txy)
         pv[:, :3, 4:6] = txy
     pv[:, 3, :] = pv[:, 0, :]
     polys = np.zeros((n, 4), dtype=np.int32)
@@ -151,18 +176,20 @@ def gen_c2(n_tris: int = 1_000_000, width: int = 1920, height: int = 1080, log_f
 
 def gen_c3(n_tris: int = 10_000_000, width: int = 3840, height: int = 2160, log_focus: int = 11,
            radius: int = 8, seed: int = 0xC0FFEE03, equal_lights: bool = True,
-           lin_percent: int = 90, cull: str = "random") -> Scene:
+           lin_percent: int = 90, cull: str = "random", regular_mapping: bool = False) -> Scene:
     """Texture-mapped triangles that exercise the view-volume, near-plane and screen
     clippers: centres uniform over the screen plus a quarter-screen margin, depth
     4..4095, one 256x256 texture, texture coordinates 0..1023.  `lin_percent` of the
     triangles keep their first vertex at z >= 1024 so that they take the linear mapper.
-    equal_lights=True gives each triangle one light value for all three vertices."""
+    equal_lights=True gives each triangle one light value for all three vertices.
+    regular_mapping=True keeps out the (few per million) random texture mappings on which
+    the reference itself divides by zero."""
     rng = Rng(seed)
     verts, polys, pv = _triangles(rng, n_tris, width, height, log_focus, radius,
                                   (-(width // 4), width + width // 4 - 1),
                                   (-(height // 4), height + height // 4 - 1), (4, 4095), cull,
                                   rgb_equal=equal_lights, tex=True, first_z_min=1024,
-                                  first_z_frac=lin_percent)
+                                  first_z_frac=lin_percent, regular_mapping=regular_mapping)
     aux = np.zeros((n_tris, 4), dtype=np.int32)
     aux[:, 3] = M_PLANNAR | (8 << 8)
     return Scene(width, height, log_focus, M_TEXTURED, verts, polys, pv, polyaux=aux,

@@ -99,6 +99,62 @@ def test_c3_clipped_textured_4k_subset(env):
     assert gc["unsupported_polys"] == ocn["unsupported"] == 1
     assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
     assert gc["fragments"] == ocn["fragments"]
+    assert gc["polys_drawn"] == ocn["polys_drawn"]      # includes triangles wholly beyond a screen border
+
+
+def test_offscreen_triangles_count_as_drawn(env):
+    """triangles wholly beyond one screen border but inside the 90-degree view volume: the
+    clippers drop every edge, nothing is drawn, polys_drawn still counts the front-facing ones"""
+    P, G = env
+    W, H, lf = 320, 200, 9
+    rng = S.Rng(77)
+    n = 4000
+    sc = S.gen_c2(n, W, H, lf, radius=10, seed=4242)
+    # push every triangle past a border: shift view x or y by a multiple of its depth
+    v = sc.verts.copy()
+    side = rng.ints(0, 3, n).repeat(3)
+    z = v[:, 2]
+    v[:, 0] = np.where(side == 0, v[:, 0] - ((z * (W + 80)) >> lf), np.where(side == 1, v[:, 0] + ((z * (W + 80)) >> lf), v[:, 0]))
+    v[:, 1] = np.where(side == 2, v[:, 1] - ((z * (H + 80)) >> lf), np.where(side == 3, v[:, 1] + ((z * (H + 80)) >> lf), v[:, 1]))
+    sc.verts = v
+    c, z, oc, oz, gc, ocn = _render_both(P, G, sc)
+    assert (z == oz).all() and (c == oc).all()
+    assert gc["fragments"] == ocn["fragments"] == 0
+    assert gc["polys_drawn"] == ocn["polys_drawn"] > 0
+
+
+@pytest.mark.parametrize("layout", ["soup", "odd-first", "shuffled-vertices", "shuffled-records", "tail"])
+def test_input_layouts_take_the_same_picture(env, layout):
+    """The fast set-up kernel reads a wave's records and vertices as one block when they lie
+    in sequence (a triangle soup) and gathers them otherwise: every layout of the same
+    triangles must give the same frame."""
+    P, G = env
+    W, H = 640, 480
+    n = 64 * 40 + (17 if layout == "tail" else 0)
+    sc = S.gen_c2(n, W, H, 9, radius=12, seed=606)
+    rng = np.random.default_rng(5)
+    if layout == "odd-first":                      # records start at an odd index: no 16-byte alignment
+        sc.polyverts = np.concatenate([np.zeros((1, 6), np.int32), sc.polyverts])
+        sc.polys = sc.polys.copy()
+        sc.polys[:, 3] += 1
+    elif layout == "shuffled-vertices":            # same records, vertex array permuted
+        perm = rng.permutation(sc.verts.shape[0])
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(perm.size)
+        sc.verts = sc.verts[perm]
+        sc.polyverts = sc.polyverts.copy()
+        sc.polyverts[:, 0] = inv[sc.polyverts[:, 0]]
+    elif layout == "shuffled-records":             # record groups permuted, polygons point at them
+        perm = rng.permutation(n)
+        pv = sc.polyverts.reshape(n, 4, 6)
+        sc.polyverts = pv[perm].reshape(-1, 6)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(n)
+        sc.polys = sc.polys.copy()
+        sc.polys[:, 3] = inv * 4
+    c, z, oc, oz, gc, ocn = _render_both(P, G, sc)
+    assert (z == oz).all() and (c == oc).all()
+    assert gc["fragments"] == ocn["fragments"] and gc["polys_drawn"] == ocn["polys_drawn"]
 
 
 def test_c2_small_subset_1080p(env):
