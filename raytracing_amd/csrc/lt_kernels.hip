@@ -1337,19 +1337,19 @@ __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
 
 // One workgroup per screen tile; LDS holds the tile's packed (depth, draw index) keys.
 //
-// Depth pass.  Lanes take the tile's polygons one each.  A polygon that is small inside
-// this tile is walked by its lane: row by row, pixel by pixel, lowering keys with
-// ds_min_u64.  A polygon that covers many pixels of the tile is left to the whole wave:
-// its rows are evaluated one per lane, then each row's span is swept 64 pixels per step,
-// one pixel per lane.  No lane waits for another workgroup-wide: the minimum is
-// commutative, so there are no barriers between polygons.
+// Depth pass.  Lanes take the tile's polygons one each and publish their depth-pass data
+// in LDS; the rows of a wave's 64 polygons inside the tile are then numbered through a
+// prefix sum and dealt one row per lane, whatever the polygon heights, and each lane walks
+// its row pixel by pixel, lowering keys with ds_min_u64.  (A wave-wide sweep of large
+// polygons, one pixel column per lane, was measured slower than this for every polygon
+// size: it leaves most lanes idle on all but full-width spans.)  No lane waits for another
+// workgroup-wide: the minimum is commutative, so there are no barriers between polygons.
 //
 // Colour pass.  After a barrier every pixel of the tile knows its winner.  Each lane
 // takes pixels, looks up the winner's row (ends, start values, increments) and computes
 // that one colour: CL_light of the base colour or texel (GraphicsPoly.cpp:372,486).
 // Pixels that no polygon of this batch won keep what the frame held (or the clear
 // colour).  The frame is read (depth only) at most once per tile and written once.
-constexpr int BIG_AREA = 192;       // bounding box pixels inside the tile from which a polygon goes to the wave path
 
 template <int NA>
 __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
@@ -1425,15 +1425,14 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         poly_c = poly_n; poly_n = poly_nn;
         h_c = h_n; e0_c = e0_n; e1_c = e1_n; e2_c = e2_n;
         const bool live = poly >= 0 && r0 < r1 && cx0 <= cx1;
-        const bool big = live && (r1 - r0) * (cx1 - cx0 + 1) >= BIG_AREA;
 
-        // small polygons: their rows inside the tile are numbered through a wave-wide
+        // the rows of this round's polygons inside the tile are numbered through a wave-wide
         // prefix sum and dealt one row per lane, 64 rows per step, so lanes stay busy
         // whatever the mix of polygon heights.  A lane publishes its polygon's depth-pass
         // data in the wave's own LDS staging rows; the lane that draws a row reads the
         // owner's data back (ordering inside one wave: LDS operations complete in issue order).
         {
-            const int cnt = (live && !big) ? r1 - r0 : 0;
+            const int cnt = live ? r1 - r0 : 0;
             int incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -1489,46 +1488,6 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                 }
             }
             __builtin_amdgcn_wave_barrier();
-        }
-
-        // large polygons: the wave takes them one after another.  The polygon's lane and
-        // the row number are wave-uniform, so the broadcasts are register reads
-        // (v_readlane), not LDS permutes.
-        unsigned long long bigmask = __ballot(big);
-        while (bigmask) {
-            const int src = __ffsll((long long)bigmask) - 1;
-            bigmask &= bigmask - 1;
-            const int bpoly = rdlane(poly, src), bne = rdlane(ne, src);
-            const int br0 = rdlane(r0, src), br1 = rdlane(r1, src);
-            Edge4 be[3];
-#pragma unroll
-            for (int e = 0; e < 3; e++) {
-                be[e].xy1 = rdlane(ed[e].xy1, src); be[e].xy2 = rdlane(ed[e].xy2, src);
-                be[e].z0 = rdlane(ed[e].z0, src);   be[e].zi = rdlane(ed[e].zi, src);
-            }
-            const unsigned id = (unsigned)bpoly + 1u;
-            // rows of the tile are at most TH <= 64: lane l evaluates row br0 + l
-            int beg = 0, end = -1, zs = 0, zi = 0;
-            {
-                const int y = br0 + lane;
-                bool ok = false;
-                if (y < br1)
-                    ok = bne <= 3 ? depth_row3(be, bne, y, beg, end, zs, zi)
-                                  : depth_row_mem(a.edges, ESZ / 4, a.np, bpoly, bne, y, beg, end, zs, zi);
-                if (!ok) { beg = 0; end = -1; }
-            }
-            // depth at this lane's pixel column if the span started there: z = zc + x*zi
-            const int x = tx0 + lane;                       // TW == 64: one pixel column per lane
-            const int zc = wsub(zs, wmul(beg, zi));
-            const int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
-            if (xa <= xb) frags += (unsigned long long)(xb - xa + 1);
-            const int nrows = br1 - br0;
-            unsigned long long *kcol = keys + (br0 - ty0) * TW + lane;
-            for (int rr = 0; rr < nrows; rr++) {
-                const int rbeg = rdlane(beg, rr), rend = rdlane(end, rr);
-                const int rzc = rdlane(zc, rr), rzi = rdlane(zi, rr);
-                if (x >= rbeg && x <= rend) atomicMin(&kcol[rr * TW], depth_key(wadd(rzc, wmul(x, rzi)) >> 16, id));
-            }
         }
     }
     __syncthreads();
