@@ -1355,7 +1355,10 @@ template <int NA>
 __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
 {
     constexpr int ESZ = edge_ints(NA);
-    __shared__ unsigned long long keys[TH * TW];
+    // rows are KW keys apart: with a stride of exactly TW every row would start in the same
+    // LDS bank, and the lanes of the depth pass walk different rows at similar columns
+    constexpr int KW = TW + 1;
+    __shared__ unsigned long long keys[TH * KW];
     __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 lanes x {edge0, edge1, edge2, {poly, ne, r0, offset}}
 
     const int t = threadIdx.x, lane = t & 63;
@@ -1374,7 +1377,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
         int z = INT_MAX;
         if (!a.clear_pending && gx < a.W && gy < a.H) z = a.zbuf[(size_t)gy * a.W + gx];
-        keys[p] = depth_key(z, 0u);
+        keys[ly * KW + lx] = depth_key(z, 0u);
     }
     __syncthreads();
 
@@ -1477,7 +1480,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                         const int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
                         if (xa <= xb) {
                             frags += (unsigned long long)(xb - xa + 1);
-                            unsigned long long *krow = keys + (y - ty0) * TW - tx0;
+                            unsigned long long *krow = keys + (y - ty0) * KW - tx0;
                             int z = wadd(zs, wmul(xa - beg, zi));
                             for (int x = xa; x <= xb; x++) {
                                 atomicMin(&krow[x], depth_key(z >> 16, id));
@@ -1504,7 +1507,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
 #pragma unroll
         for (int g = 0; g < CG; g++) {
             const int p = p0 + g * RASTER_THREADS;
-            kk[g] = p < TW * TH ? keys[p] : 0ull;
+            kk[g] = p < TW * TH ? keys[(p / TW) * KW + p % TW] : 0ull;
             hh[g] = zero4;
 #pragma unroll
             for (int e = 0; e < 3; e++) xy[g][e] = make_int2(0, 0);
