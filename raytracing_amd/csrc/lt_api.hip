@@ -188,7 +188,9 @@ int ensure_zeroed(lt_ctx *c, DevBuf &b, size_t bytes)
     if (bytes <= b.cap) return LT_OK;
     int rc = ensure(c, b, bytes);
     if (rc) return rc;
-    HIPCHK(c, hipMemset(b.p, 0, b.cap));
+    // on the stream whose kernels use the array first: the context's own streams do not
+    // wait for the default stream
+    HIPCHK(c, hipMemsetAsync(b.p, 0, b.cap, c->gs));
     return LT_OK;
 }
 
@@ -374,6 +376,8 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     CREATECHK(hipMalloc((void **)&c->tex_log_d, sizeof(int) * LT_MAX_TEXTURES));
     CREATECHK(hipMemset((void *)c->tex_ptr_d, 0, sizeof(int *) * LT_MAX_TEXTURES));
     CREATECHK(hipMemset(c->tex_log_d, 0, sizeof(int) * LT_MAX_TEXTURES));
+    // the fills above ran on the default stream, which the context's own streams do not wait for
+    CREATECHK(hipDeviceSynchronize());
 #undef CREATECHK
     // the frame's contents are undefined until lt_clear, as after G_init_graphics
     *out = c;

@@ -117,6 +117,16 @@ __global__ void __launch_bounds__(256) transform_kernel(Mat12 M, const int4 *__r
     d[2] = o[2];
 }
 
+// Lanes of one wave exchange data through LDS: the wave's LDS operations complete in issue
+// order, so all this needs is that the compiler keeps the order (a release fence limited
+// to LDS: a full fence would also wait for every global access in flight, prefetches
+// included).
+#define LDS_WAVE_SYNC()                                                    \
+    do {                                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");    \
+        __builtin_amdgcn_wave_barrier();                                   \
+    } while (0)
+
 // lane `l` of v, l wave-uniform
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
@@ -352,14 +362,13 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
         // and hands each lane its 96 bytes through LDS: a lane-per-record gather would
         // touch 64 different cache lines per load instruction.
         const int first0 = rdlane(first, 0);
-        const bool rec_seq = wave_full && __ballot(!slow && first == first0 + 4 * lane) == ~0ull && (first0 & 1) == 0 &&
+        const bool rec_seq = wave_full && __ballot(!slow && first == first0 + 4 * lane) == ~0ull && (first0 & 1) == 0 && ((size_t)a.polyverts & 15) == 0 &&
                              (long long)first0 + 256 <= (long long)a.npv;
         if (rec_seq) {
             const int4 *blk = (const int4 *)(a.polyverts + (size_t)first0 * 6);
 #pragma unroll
             for (int k = 0; k < 6; k++) stg[k * 64 + lane] = blk[k * 64 + lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            LDS_WAVE_SYNC();
             int r[24];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
@@ -397,8 +406,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
             const int4 *blk = (const int4 *)a.verts + v0;
 #pragma unroll
             for (int k = 0; k < 3; k++) stg[k * 64 + lane] = blk[k * 64 + lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            LDS_WAVE_SYNC();
 #pragma unroll
             for (int i = 0; i < 3; i++) pv[i] = stg[lane * 3 + i];
             pv[3] = pv[0];
@@ -875,10 +883,10 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
         // second stage: only the polygons that the fast kernel passed on.  Sub-queue
         // blockIdx.y is shared by the few workgroups of row y of the grid, which stride
         // through it; its length is only known on the device.
-        const unsigned cnt = a.queue_count[blockIdx.y * QUEUE_COUNT_STRIDE];
+        const unsigned cnt = min(a.queue_count[blockIdx.y * QUEUE_COUNT_STRIDE], a.queue_cap);
         for (unsigned qi = blockIdx.x * blockDim.x + threadIdx.x; qi < cnt; qi += gridDim.x * blockDim.x) {
             const uint2 e = a.queue[(size_t)blockIdx.y * a.queue_cap + qi];
-            setup_one<DIM, SCREEN>(a, (int)e.x, (int)e.y);
+            if (e.x < (unsigned)a.np && e.y < (unsigned)a.np) setup_one<DIM, SCREEN>(a, (int)e.x, (int)e.y);
         }
     } else {
         const int poly = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1392,8 +1400,12 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     // list entries are dealt to the waves in turn (entry e of a round goes to wave e % 4),
     // so a short list or a short last round still gives every wave its share
     const unsigned slot = (unsigned)(lane * (RASTER_THREADS / 64) + (t >> 6));
+    // (an entry that is not a polygon of this batch is dropped: unsigned compare)
+    const unsigned npu = (unsigned)a.np;
     int poly_c = slot < lcnt ? (int)a.tile_list[lbeg + slot] : -1;
     int poly_n = RASTER_THREADS + slot < lcnt ? (int)a.tile_list[lbeg + RASTER_THREADS + slot] : -1;
+    if ((unsigned)poly_c >= npu) poly_c = -1;
+    if ((unsigned)poly_n >= npu) poly_n = -1;
     int4 h_c = zero4, e0_c = zero4, e1_c = zero4, e2_c = zero4;
     if (poly_c >= 0) {
         h_c = ((const int4 *)a.hdr)[poly_c];
@@ -1410,7 +1422,8 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
             e2_n = *edge_piece(a.edges, a.np, ESZ / 4, 2, 0, poly_n);
         }
         const unsigned li2 = (rd + 2) * RASTER_THREADS + slot;
-        const int poly_nn = li2 < lcnt ? (int)a.tile_list[lbeg + li2] : -1;
+        int poly_nn = li2 < lcnt ? (int)a.tile_list[lbeg + li2] : -1;
+        if ((unsigned)poly_nn >= npu) poly_nn = -1;
 
         const int poly = poly_c;
         int ne = 0, r0 = 0, r1 = 0, cx0 = 0, cx1 = -1;
@@ -1448,8 +1461,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
             st[lane * 4 + 1] = make_int4(ed[1].xy1, ed[1].xy2, ed[1].z0, ed[1].zi);
             st[lane * 4 + 2] = make_int4(ed[2].xy1, ed[2].xy2, ed[2].z0, ed[2].zi);
             st[lane * 4 + 3] = make_int4(poly, ne, r0, incl - cnt);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            LDS_WAVE_SYNC();
             for (int rb = 0; rb < total; rb += 64) {
                 const int r = rb + lane;
                 if (r < total) {

@@ -86,3 +86,26 @@ def test_caller_stream_produces_inputs(env):
     orc.render_polys(P.transform(m, sc.verts), sc.polys, None, sc.polyverts, sc.render_type, sc.log_focus)
     assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
     ctx.close()
+
+
+def test_first_batches_of_fresh_contexts(env):
+    """A context's first two batches use work arrays that were just allocated and zeroed;
+    the zero fill must be ordered before the kernels of the context's own streams (queued
+    polygons went missing, and tile lists read stale entries, when it was not)."""
+    P, G = env
+    sc = S.gen_fuzz_polys(80, 160, 120, 7, 504, render_type=S.M_TEXTURED, textured=True, equal_lights=True,
+                          zrange=(12, 900))
+    orc = P.Oracle(sc.width, sc.height)
+    for h, (tex, lg) in enumerate(sc.textures):
+        orc.set_texture(h, tex, lg)
+    orc.clear(0x102030, 255, 255, 255)
+    orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type,
+                     sc.log_focus, sc.force_linear)
+    for _ in range(25):
+        ctx = G.Context(sc.width, sc.height)
+        for _ in range(3):
+            ctx.clear(P.cl_light(0x102030, 255, 255, 255))
+            ctx.submit_scene(sc)
+            c, z = ctx.readback()
+            assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+        ctx.close()
