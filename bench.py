@@ -48,6 +48,30 @@ def make_scene(workload, tris):
     raise SystemExit(f"unknown workload {workload}")
 
 
+STAGE_KERNEL = {"fill": "raster_kernel", "setup": "setup_fast_kernel", "bin": "scatter_kernel", "scan": "count_kernel"}
+
+
+def measured_traffic(workload, tris, stage):
+    """HBM-side bytes per launch of the stage's main kernel from the committed counter passes
+    (profiles/: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this
+    benchmark, KiB per launch).  Only for the workload the passes were taken on."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_c2small.json")
+    if workload != "c2-small" or tris != 1_000_000 or not os.path.exists(path):
+        return None, None
+    pmc = json.load(open(path))
+    for name, ctrs in pmc.items():
+        if STAGE_KERNEL.get(stage, "?") in name and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
+            f, w = ctrs["FETCH_SIZE"]["mean_per_launch"], ctrs["WRITE_SIZE"]["mean_per_launch"]
+            head = f"rocprofv3 FETCH_SIZE {f:.0f} KiB + WRITE_SIZE {w:.0f} KiB per launch of {name.split('(')[0]}; "
+            if stage == "setup":
+                # 16-byte-per-lane streaming reads: gfx950 reports half their bytes
+                return int((2 * f + w) * 1024), head + "FETCH_SIZE doubled (16-byte-per-lane streaming reads are counted at half)"
+            return int((f + w) * 1024), head + ("FETCH_SIZE as reported (this kernel gathers 16-byte pieces, a width the gfx950 "
+                                                "halving rule is not calibrated for; it counts memory-side requests, Infinity "
+                                                "Cache hits included)")
+    return None, None
+
+
 def cpu_baseline(sc, passes, want_frame=True):
     """Time the CPU checker on the same scene; returns (dict, colour, depth)."""
     import oracle.port as P
@@ -184,6 +208,7 @@ def main():
         frame_bytes = BYTES_PER_TRI * sc.n_polys + BYTES_PER_PIXEL * sc.width * sc.height
         dom_ms = stages[dom] / max(submits, 1)
         achieved = frame_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic, traffic_note = measured_traffic(args.workload, sc.n_polys, dom)
         out = {
             "metric": "Z-tested shaded Mfragments/s + Mtris/s at 1080p/4K, 1/2/4/8 MI355X",
             "value": round(total_tris / dt_max / 1e6, 3),
@@ -209,7 +234,8 @@ def main():
             "stage_ms_measured_on": f"{warm_submits} warm-up frame(s), all stages timed; roofline.kernel is timed "
                                     f"alone over the {submits} measured frames",
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_note": traffic_note,
                          "kernel_ms": round(dom_ms, 4),
                          "algorithmic_bytes_per_launch": frame_bytes,
                          "whole_step_frac": round(frame_bytes / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
