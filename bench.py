@@ -113,6 +113,9 @@ def main():
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--split", default="frames", choices=["frames", "bands"])
     ap.add_argument("--no-pipelining", action="store_true", help="issue every kernel on one stream")
+    ap.add_argument("--host-arrays", action="store_true",
+                    help="submit from host memory (the boundary's host-pointer entry point): PCIe-inclusive rate, "
+                         "reported for reference, never the headline value")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
     args = ap.parse_args()
 
@@ -154,7 +157,11 @@ def main():
             ctx.set_band(y0, y1)
 
     def step():
-        if not bands or y0 < y1:
+        if args.host_arrays:
+            ctx.clear(0)
+            ctx.submit_object(sc.verts, sc.polys, sc.polyverts, sc.render_type, sc.log_focus, polyaux=sc.polyaux,
+                              matrix=sc.matrix, force_linear=sc.force_linear, max_edges=3)
+        elif not bands or y0 < y1:
             ctx.clear(0)
             ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux,
                                   matrix=sc.matrix, force_linear=sc.force_linear, max_edges=3)
@@ -221,7 +228,7 @@ def main():
             "scaling": "strong" if bands else "weak",
             "vs_baseline": None,
             "dtype": "int32",
-            "data": "synthetic",
+            "data": "synthetic" + (", submitted from host memory every frame (PCIe-inclusive)" if args.host_arrays else ""),
             "config": {"workload": f"{args.workload}: {sc.n_polys} Gouraud Z-buffered triangles per frame at "
                                    f"{sc.width}x{sc.height}, one frame per step per GPU"
                        if args.workload.startswith("c2") else
