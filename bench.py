@@ -104,6 +104,73 @@ def cpu_baseline(sc, passes, want_frame=True):
     return base, c, z
 
 
+def bench_shade(args, rank, local_rank, world):
+    """--workload shade: the shading pre-pass (M_shade_polygon_object) alone, one call per
+    step over `--tris` triangles (four vertex records each), four lights, arrays in HBM."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import gpu as G, scenes as S
+    case = S.gen_shading_case(args.tris, 0x5EED, n_verts=3 * args.tris, n_normals=args.tris)
+    case["polys"][:, 2] = 3
+    case["polys"][:, 3] = np.arange(args.tris, dtype=np.int32) * 4
+    case["polyverts"] = case["polyverts"][: 4 * args.tris].copy()
+    case["polynormals"] = case["polynormals"][: 4 * args.tris].copy()
+    # a triangle soup as in the rasterization workloads: vertices 3p, 3p+1, 3p+2, 3p; one normal per triangle
+    tri = np.arange(args.tris, dtype=np.int32)
+    case["polyverts"][:, 0] = (3 * tri[:, None] + np.array([0, 1, 2, 0], np.int32)[None, :]).reshape(-1)
+    case["polynormals"] = np.repeat(tri, 4).astype(np.int32)
+    dev = torch.device("cuda", local_rank)
+    d = {k: torch.from_numpy(v).to(dev) for k, v in case.items() if k != "lights"}
+    d_aux = torch.zeros((args.tris, 4), dtype=torch.int32, device=dev)
+    ctx = G.Context(64, 64, device=local_rank)
+    from raytracing_amd.transform import self_matrix
+    s9 = self_matrix(31, 200, 99)
+
+    def step():
+        ctx.shade_object_dev(s9, (100, -50, 400), d["verts"], d["normals"], d["polys"], d["polyverts"], d["polynormals"],
+                             d_aux, case["lights"])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        recs = 4 * args.tris
+        # per record: 24 B record read + 12 B written, 16 B vertex, 16 B normal, 4 B normal index; per polygon 16 + 12 B
+        algo = recs * (24 + 12 + 16 + 16 + 4) + args.tris * (16 + 12)
+        ms = dt / args.steps * 1e3
+        out = {"metric": "shaded vertex records per second (shading pre-pass)", "value": round(recs * world / (ms * 1e-3) / 1e6, 2),
+               "unit": "Mrecords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/int64", "data": "synthetic",
+               "config": {"workload": f"shade: soup of {args.tris} triangles, {recs} vertex records, 4 lights (ambient, 2 point, direct)"},
+               "roofline": {"bound": "hbm", "kernel": "shade_kernel", "achieved": round(algo / (ms * 1e-3) / 1e9, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                            "traffic": None, "algorithmic_bytes_per_launch": algo}}
+        if not args.no_cpu:
+            import oracle.port as P
+            n = min(args.tris, 200_000)
+            t0 = time.perf_counter()
+            P.shade_polys(s9, (100, -50, 400), case["verts"], case["normals"], case["polys"][:n], case["polyverts"],
+                          case["polynormals"], None, case["lights"])
+            out["cpu_baseline"] = {"value": round(4 * n / (time.perf_counter() - t0) / 1e6, 3), "unit": "Mrecords/s", "cores": 1,
+                                   "kind": "port", "sample": f"the first {n} triangles, 1 thread"}
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +200,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "shade":
+        bench_shade(args, rank, local_rank, world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     sc = make_scene(args.workload, args.tris)
     dev = torch.device("cuda", local_rank)
     d_verts = torch.from_numpy(sc.verts).to(dev)

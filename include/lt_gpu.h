@@ -66,6 +66,7 @@ typedef struct lt_counters {
     uint64_t order_dependent_rows; /* textured rows whose light varies along the span (GraphicsPoly.cpp:485-493) */
     uint64_t unsupported_polys;
     uint64_t list_overflow;    /* tile references that did not fit */
+    uint64_t zero_light_vectors; /* shading: (vertex, point light) pairs at zero distance, that light left out */
 } lt_counters;
 
 /* --- context ------------------------------------------------------------------ */
@@ -154,6 +155,42 @@ int lt_texture_upload(lt_ctx *ctx, int handle, const int32_t *texels, int log_si
  * T_cancatinate_self_world, TransBs.cpp:325-361).  d_from and d_to are DEVICE
  * pointers to int32[n][4]; the 4th lane of d_to is left untouched. */
 int lt_transform(lt_ctx *ctx, const int32_t m[12], const int32_t *d_from, int32_t *d_to, int n);
+
+/* struct M_light (Engine.h:116-130, _RGB_): type M_AMBIENT 1, M_POINT 2, M_DIRECT 4
+ * (Engine.h:112-114); param = position (point) or direction (direct), 4th element unused. */
+typedef struct lt_light {
+    int32_t type;
+    int32_t param[4];
+    int32_t red, green, blue;
+} lt_light;
+#define LT_MAX_LIGHTS 16
+
+/* M_shade_polygon_object (EngPoly.cpp:464-493) on device arrays: vertices and normals are
+ * rotated by the self rotation s9 = {sx1 sy1 sz1, sx2 sy2 sz2, sx3 sy3 sz3} of
+ * T_set_self_rotation (TransBs.cpp:144-183) and the vertices moved by (x, y, z); then
+ * M_shade_polygon (EngBase.cpp:325-364) gives every vertex record of every polygon its
+ * R,G,B (d_polyverts[*][1..3] are overwritten) through M_shade_vertex (EngBase.cpp:220-288)
+ * and the polygon its flat illumination (d_polyaux[p][0..2] = m_red, m_green, m_blue).
+ * d_normals int32[nn][4] are the object's unit normals scaled by 1<<7 (m_normals of
+ * M_polygon_object), d_polynormals[npv] the normal index of each record (m_normals of
+ * M_polygon).  Runs on the caller's stream (lt_set_stream), so a submit that follows sees
+ * the result.  A point light at zero distance from a vertex stops the reference
+ * (T_unit_vector, TransLn.cpp:185); here that light is left out for that vertex and
+ * lt_flush reports LT_ERR_UNSUPPORTED.  Polygons with records or indices out of range are
+ * left alone and reported as LT_ERR_OVERFLOW. */
+int lt_shade_object_dev(lt_ctx *ctx, const int32_t s9[9], int32_t x, int32_t y, int32_t z,
+                        const int32_t *d_verts, int nv, const int32_t *d_normals, int nn,
+                        const int32_t *d_polys, int np, int32_t *d_polyverts,
+                        const int32_t *d_polynormals, int npv, int32_t *d_polyaux,
+                        const lt_light *lights, int nlights);
+/* The same on host arrays, as the reference's caller holds them: polyverts and polyaux are
+ * copied to the device, shaded and copied back before the call returns (M_shade_polygon_object
+ * writes into the polygons' own records, EngBase.cpp:339-352). */
+int lt_shade_object(lt_ctx *ctx, const int32_t s9[9], int32_t x, int32_t y, int32_t z,
+                    const int32_t *verts, int nv, const int32_t *normals, int nn,
+                    const int32_t *polys, int np, int32_t *polyverts,
+                    const int32_t *polynormals, int npv, int32_t *polyaux,
+                    const lt_light *lights, int nlights);
 
 /* M_render_polygon_object (EngPoly.cpp:499-525) for one object of np polygons, after
  * the host has built the matrix (T_set_self_rotation + T_cancatinate_self_world):

@@ -758,3 +758,149 @@ void lto_render_polys(lto_ctx *c,const i32 *viewverts,const i32 *polys,const i32
         render_polygon(c,viewverts,polys+(size_t)i*4,polyaux?polyaux+(size_t)i*4:NULL,
                        polyverts,render_type,force_linear);
 }
+
+/* ------------------------------------------------------------------ shading pre-pass
+ *
+ * M_shade_polygon_object (EngPoly.cpp:464-493): vertices and normals are rotated by the
+ * object's self rotation, vertices translated to world space, then every polygon's vertex
+ * records receive R,G,B from the light list, and the polygon its flat illumination.
+ * Lights: {type, px, py, pz, pw, red, green, blue} (struct M_light, Engine.h:116-130);
+ * type 1 ambient, 2 point, 4 direct (M_AMBIENT / M_POINT / M_DIRECT, Engine.h:112-114);
+ * any other type contributes nothing (the switch of M_shade_vertex has no default). */
+
+#define LTO_LOG_NORMAL 7                    /* T_LOG_NORMAL_SIZE, Trans.h:29 */
+
+/* T_set_self_rotation alone (TransBs.cpp:144-183): s[9] = sx1 sy1 sz1 sx2 ... sz3 */
+void lto_self_matrix(int variant,int alp,int bet,int gam,i32 *s)
+{
+    i32 S[256],C[256];
+    lto_trig_tables(variant,S,C);
+    self_rotation(S,C,(unsigned char)alp,(unsigned char)bet,(unsigned char)gam,s);
+}
+
+/* T_self_rotation, TransBs.cpp:194-214 (products wrap in 32 bits, then >>T_P) */
+static void self_rotate(const i32 *s,const i32 *from,i32 *to)
+{
+    i32 x=from[0],y=from[1],z=from[2];
+    to[0]=wadd(wadd(FX(s[0],x),FX(s[1],y)),FX(s[2],z));
+    to[1]=wadd(wadd(FX(s[3],x),FX(s[4],y)),FX(s[5],z));
+    to[2]=wadd(wadd(FX(s[6],x),FX(s[7],y)),FX(s[8],z));
+}
+
+/* TI_sqrt, TransLn.cpp:38-51: 16 result bits, 64-bit accumulators on LP64 */
+static uint64_t ti_sqrt(uint64_t arg)
+{
+    int i;
+    uint64_t nprd,msk=0x8000,val=0,prd=0;
+    for(i=15;i>=0;i--)
+    {
+        nprd=prd+(val<<(i+1))+(msk<<i);
+        if(nprd<=arg){ val|=msk; prd=nprd; }
+        msk>>=1;
+    }
+    return val;
+}
+
+/* T_norm, TransLn.cpp:75-103 (fixed-point branch); long is 64 bits in the pinned build */
+static i64 t_norm(const i32 *v)
+{
+    if((v[0]>0xffff)||(v[1]>0xffff)||(v[2]>0xffff)||(v[0]<-0xffff)||(v[1]<-0xffff)||(v[2]<-0xffff))
+        return (i64)(ti_sqrt((uint64_t)((((i64)v[0])>>8)*v[0]+(((i64)v[1])>>8)*v[1]+(((i64)v[2])>>8)*v[2]))<<4);
+    return (i64)ti_sqrt((uint64_t)(((i64)v[0])*v[0]+((i64)v[1])*v[1]+((i64)v[2])*v[2]));
+}
+
+/* T_unit_vector, TransLn.cpp:175-190; returns 0 where the reference stops with
+ * "Found a zero length vector" */
+static int unit_vector(const i32 *from1,const i32 *from2,i32 *to)
+{
+    i32 v[3];
+    i64 lng;
+    v[0]=wsub(from2[0],from1[0]); v[1]=wsub(from2[1],from1[1]); v[2]=wsub(from2[2],from1[2]);
+    lng=t_norm(v);
+    if(lng==0) return 0;
+    /* (long)v << 7 as the reference writes it: a multiplication keeps negative values defined */
+    to[0]=(i32)((((i64)v[0])*(1<<LTO_LOG_NORMAL))/lng);
+    to[1]=(i32)((((i64)v[1])*(1<<LTO_LOG_NORMAL))/lng);
+    to[2]=(i32)((((i64)v[2])*(1<<LTO_LOG_NORMAL))/lng);
+    return 1;
+}
+
+/* T_scalar_product, TransLn.cpp:201-208 */
+static i32 scalar_product(const i32 *a,const i32 *b)
+{
+    return (i32)((((i64)a[0]*(i64)b[0])+((i64)a[1]*(i64)b[1])+((i64)a[2]*(i64)b[2]))>>LTO_LOG_NORMAL);
+}
+
+/* M_shade_vertex, EngBase.cpp:220-288 (_RGB_); returns the number of lights skipped
+ * because the reference would have stopped on a zero-length vector */
+static int shade_vertex(i32 *rgb,const i32 *vertex,const i32 *normal,int nl,const i32 *lights)
+{
+    int j,skipped=0;
+    rgb[0]=rgb[1]=rgb[2]=0;
+    for(j=0;j<nl;j++)
+    {
+        const i32 *l=lights+j*8;
+        i32 lv[3],prd;
+        if(l[0]==1){ rgb[0]=wadd(rgb[0],l[5]); rgb[1]=wadd(rgb[1],l[6]); rgb[2]=wadd(rgb[2],l[7]); }
+        else if(l[0]==2)
+        {
+            if(!unit_vector(vertex,l+1,lv)){ skipped++; continue; }
+            prd=scalar_product(lv,normal);
+            if(prd<0) continue;
+            rgb[0]=wadd(rgb[0],wmul(prd,l[5])>>LTO_LOG_NORMAL);
+            rgb[1]=wadd(rgb[1],wmul(prd,l[6])>>LTO_LOG_NORMAL);
+            rgb[2]=wadd(rgb[2],wmul(prd,l[7])>>LTO_LOG_NORMAL);
+        }
+        else if(l[0]==4)
+        {
+            prd=(i32)(0u-(u32)scalar_product(l+1,normal));
+            if(prd<0) continue;
+            rgb[0]=wadd(rgb[0],wmul(prd,l[5])>>LTO_LOG_NORMAL);
+            rgb[1]=wadd(rgb[1],wmul(prd,l[6])>>LTO_LOG_NORMAL);
+            rgb[2]=wadd(rgb[2],wmul(prd,l[7])>>LTO_LOG_NORMAL);
+        }
+    }
+    return skipped;
+}
+
+/* M_shade_polygon_object + M_shade_polygon (EngPoly.cpp:464-493, EngBase.cpp:325-364).
+ * s9: self rotation; (x,y,z): object position.  verts[nv][4], normals[nn][4];
+ * polys[np][4] = {colour, tex, n_edges, first}; polyverts[*][6]: R,G,B of every record of
+ * every polygon are overwritten; polynormals[*]: normal index per record (m_normals);
+ * polyaux[np][4]: m_red, m_green, m_blue overwritten with the flat illumination.
+ * Returns the number of (vertex, light) pairs skipped for a zero-length light vector;
+ * polygons whose records, vertex or normal indices are out of range are left alone and
+ * counted in *bad_polys. */
+int lto_shade_polys(const i32 *s9,i32 x,i32 y,i32 z,const i32 *verts,int nv,const i32 *normals,int nn,
+                    const i32 *polys,int np,i32 *polyverts,const i32 *polynormals,int npv,i32 *polyaux,
+                    const i32 *lights,int nl,int *bad_polys)
+{
+    int i,k,skipped=0,bad=0;
+    for(i=0;i<np;i++)
+    {
+        int e=polys[i*4+2],ok=1;
+        i64 first=polys[i*4+3];
+        i32 sum[3]={0,0,0};
+        if(e<0||first<0||first+e+1>npv) ok=0;
+        for(k=0;ok&&k<=e;k++)
+        {
+            i32 vi=polyverts[(first+k)*6],ni=polynormals[first+k];
+            if(vi<0||vi>=nv||ni<0||ni>=nn) ok=0;
+        }
+        if(!ok){ bad++; continue; }
+        for(k=0;k<=e;k++)
+        {
+            i32 *rec=polyverts+(first+k)*6,wv[3],wn[3];
+            self_rotate(s9,verts+(size_t)rec[0]*4,wv);
+            wv[0]=wadd(wv[0],x); wv[1]=wadd(wv[1],y); wv[2]=wadd(wv[2],z);      /* T_translation, TransBs.cpp:86-100 */
+            self_rotate(s9,normals+(size_t)polynormals[first+k]*4,wn);
+            skipped+=shade_vertex(rec+1,wv,wn,nl,lights);
+            sum[0]=wadd(sum[0],rec[1]); sum[1]=wadd(sum[1],rec[2]); sum[2]=wadd(sum[2],rec[3]);
+        }
+        polyaux[i*4+0]=tdiv(sum[0],e+1);
+        polyaux[i*4+1]=tdiv(sum[1],e+1);
+        polyaux[i*4+2]=tdiv(sum[2],e+1);
+    }
+    if(bad_polys) *bad_polys=bad;
+    return skipped;
+}

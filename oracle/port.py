@@ -61,6 +61,10 @@ def lib():
         L.lto_g_polygon.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_int32] * 4 + [C.c_int]
         L.lto_g_prp_polygon.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.lto_render_polys.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] * 4
+        L.lto_self_matrix.argtypes = [C.c_int] * 4 + [C.c_void_p]
+        L.lto_shade_polys.restype = C.c_int
+        L.lto_shade_polys.argtypes = ([C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p, C.c_int] * 2 + [C.c_void_p, C.c_int]
+                                      + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
         _lib = L
     return _lib
 
@@ -208,3 +212,24 @@ def normal_z_negative(a, b, c):
 def volume_clipping(mn, mx):
     mn, mx = _i32(mn), _i32(mx)
     return lib().lto_volume_clipping(_p(mn), _p(mx))
+
+
+def self_matrix(alp, bet, gam, variant=0):
+    """T_set_self_rotation -> int32[9] = sx1 sy1 sz1 sx2 sy2 sz2 sx3 sy3 sz3."""
+    s = np.zeros(9, np.int32)
+    lib().lto_self_matrix(variant, int(alp), int(bet), int(gam), _p(s))
+    return s
+
+
+def shade_polys(s9, pos, verts, normals, polys, polyverts, polynormals, polyaux, lights):
+    """M_shade_polygon_object -> (polyverts with R,G,B, polyaux with flat r,g,b, skipped, bad_polys).
+    lights: int32[nl][8] = {type, px, py, pz, pw, red, green, blue}."""
+    s9, v, n, po = _i32(s9), _i32(verts).reshape(-1, 4), _i32(normals).reshape(-1, 4), _i32(polys).reshape(-1, 4)
+    pv, pn = _i32(polyverts).reshape(-1, 6).copy(), _i32(polynormals).reshape(-1)
+    pa = np.zeros((po.shape[0], 4), np.int32) if polyaux is None else _i32(polyaux).reshape(-1, 4).copy()
+    li = _i32(lights).reshape(-1, 8)
+    bad = C.c_int(0)
+    skipped = lib().lto_shade_polys(_p(s9), int(pos[0]), int(pos[1]), int(pos[2]), _p(v), v.shape[0], _p(n), n.shape[0],
+                                    _p(po), po.shape[0], _p(pv), _p(pn), pv.shape[0], _p(pa), _p(li), li.shape[0],
+                                    C.byref(bad))
+    return pv, pa, skipped, bad.value

@@ -162,3 +162,21 @@ class Ref:
         pa = None if polyaux is None else _i32(polyaux)
         self.L.ltref_render_object(_p(v), v.shape[0], _p(po), _p(pa), _p(pv), po.shape[0], render_type,
                                    pos[0], pos[1], pos[2], ang[0], ang[1], ang[2])
+
+    def self_matrix(self, alp, bet, gam):
+        s = np.zeros(9, np.int32)
+        self.L.ltref_self_matrix(int(alp), int(bet), int(gam), _p(s))
+        return s
+
+    def shade_object(self, verts, normals, polys, polyverts, polynormals, polyaux, pos, ang, lights):
+        """the real M_shade_polygon_object (at most 1024 vertices and normals) ->
+        (polyverts with R,G,B, polyaux with flat r,g,b)"""
+        v, n, po = _i32(verts).reshape(-1, 4).copy(), _i32(normals).reshape(-1, 4).copy(), _i32(polys).reshape(-1, 4)
+        assert v.shape[0] <= 1024 and n.shape[0] <= 1024
+        pv, pn = _i32(polyverts).reshape(-1, 6).copy(), _i32(polynormals).reshape(-1).copy()
+        pa = np.zeros((po.shape[0], 4), np.int32) if polyaux is None else _i32(polyaux).reshape(-1, 4).copy()
+        li = _i32(lights).reshape(-1, 8)
+        self.L.ltref_shade_object(_p(v), v.shape[0], _p(n), n.shape[0], _p(po), _p(pa), _p(pv), _p(pn), po.shape[0],
+                                  int(pos[0]), int(pos[1]), int(pos[2]), int(ang[0]), int(ang[1]), int(ang[2]),
+                                  _p(li), li.shape[0])
+        return pv, pa

@@ -233,3 +233,55 @@ void ltref_scan_polygon(int *tuples,int length,int dim,int *miny,int *maxy,
 }
 
 } /* extern "C" */
+
+/* ---- shading pre-pass (EngPoly.cpp:464-493) ---- */
+extern HW_32_bit T_sx1,T_sx2,T_sx3,T_sy1,T_sy2,T_sy3,T_sz1,T_sz2,T_sz3;
+
+extern "C" {
+
+/* T_set_self_rotation with the tables of this build -> s9 = sx1 sy1 sz1 sx2 .. sz3 */
+void ltref_self_matrix(int alp,int bet,int gam,int *s9)
+{
+ T_set_self_rotation((unsigned char)alp,(unsigned char)bet,(unsigned char)gam);
+ s9[0]=T_sx1; s9[1]=T_sy1; s9[2]=T_sz1;
+ s9[3]=T_sx2; s9[4]=T_sy2; s9[5]=T_sz2;
+ s9[6]=T_sx3; s9[7]=T_sy3; s9[8]=T_sz3;
+}
+
+/* The real M_shade_polygon_object; nv and nn must stay within M_MAX_OBJECT_VERTICES.
+ * lights[nl][8] = {type, px,py,pz,pw, red,green,blue}; polyverts R,G,B and polyaux
+ * m_red,m_green,m_blue are overwritten. */
+void ltref_shade_object(int *verts,int nv,int *normals,int nn,const int *polys,int *polyaux,
+                        int *polyverts,int *polynormals,int np,
+                        int x,int y,int z,int alp,int bet,int gam,const int *lights,int nl)
+{
+ std::vector<struct M_polygon> store(np);
+ std::vector<struct M_polygon*> ptrs(np);
+ std::vector<struct M_light> lstore(nl);
+ std::vector<struct M_light*> lptrs(nl);
+ struct M_polygon_object obj;
+ for(int i=0;i<np;i++)
+ {
+  fill_polygon(&store[i],polys,polyaux,polyverts,i);
+  store[i].m_normals=polynormals+polys[i*4+3];
+  ptrs[i]=&store[i];
+ }
+ for(int j=0;j<nl;j++)
+ {
+  lstore[j].m_type=lights[j*8];
+  for(int k=0;k<4;k++) lstore[j].m_parameter[k]=lights[j*8+1+k];
+  lstore[j].m_red=lights[j*8+5]; lstore[j].m_green=lights[j*8+6]; lstore[j].m_blue=lights[j*8+7];
+  lptrs[j]=&lstore[j];
+ }
+ obj.m_type=M_POLYGON_OBJECT; obj.m_order=NULL;
+ obj.m_no_polygons=np; obj.m_polygons=ptrs.data();
+ obj.m_no_vertices=nv; obj.m_vertices=verts;
+ obj.m_no_normals=nn; obj.m_normals=normals;
+ M_shade_polygon_object(&obj,x,y,z,alp,bet,gam,nl,lptrs.data());
+ for(int i=0;i<np;i++)
+ {
+  polyaux[i*4+0]=store[i].m_red; polyaux[i*4+1]=store[i].m_green; polyaux[i*4+2]=store[i].m_blue;
+ }
+}
+
+} /* extern "C" */

@@ -14,14 +14,14 @@ EXPORTS = [
     "lt_clear", "lt_flush", "lt_readback", "lt_framebuffer", "lt_get_counters", "lt_reset_counters",
     "lt_texture_upload", "lt_transform", "lt_submit_object", "lt_submit_object_dev",
     "lt_submit_screen_polys", "lt_set_profiling", "lt_get_stage_ms", "lt_set_textured_order",
-    "lt_bind_framebuffer", "lt_set_band", "lt_set_pipelining",
+    "lt_bind_framebuffer", "lt_set_band", "lt_set_pipelining", "lt_shade_object_dev", "lt_shade_object",
 ]
 
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "fragments", "polys_in", "polys_drawn", "tile_refs", "overflow_polys",
-        "order_dependent_rows", "unsupported_polys", "list_overflow")]
+        "order_dependent_rows", "unsupported_polys", "list_overflow", "zero_light_vectors")]
 
 
 _lib = None
@@ -53,6 +53,8 @@ def lib():
     L.lt_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.lt_bind_framebuffer.argtypes = [vp, vp, vp]
     L.lt_set_band.argtypes = [vp, i32, i32]
+    L.lt_shade_object_dev.argtypes = [vp, vp, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, vp, vp, i32]
+    L.lt_shade_object.argtypes = L.lt_shade_object_dev.argtypes
     L.lt_set_pipelining.argtypes = [vp, i32]
     L.lt_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.lt_reset_counters.argtypes = [vp]

@@ -54,7 +54,7 @@ struct lt_ctx {
     hipStream_t gs = nullptr, rs = nullptr;            // streams in use: own_* or `stream`
     hipEvent_t ev_fork = nullptr;
     DevBuf view;
-    DevBuf s_verts, s_polys, s_aux, s_pv;      // staging for host-pointer submits
+    DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn;      // staging for host-pointer calls
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
     int tex_log_h[LT_MAX_TEXTURES] = {};
@@ -391,7 +391,7 @@ int lt_ctx_destroy(lt_ctx *c)
     if (c->gs) (void)hipStreamSynchronize(c->gs);
     if (c->rs) (void)hipStreamSynchronize(c->rs);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->view, &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv};
+    DevBuf *bufs[] = {&c->view, &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (lt_ctx::Work &w : c->work) {
@@ -526,6 +526,13 @@ int lt_flush(lt_ctx *c)
                     "%llu textured polygon(s) name a bad texture, or take the perspective mapper with a singular "
                     "texture mapping (the reference divides by zero there) or without polyaux: not drawn", d);
     }
+    if (s.zero_light_vectors > c->base.zero_light_vectors) {
+        unsigned long long d = s.zero_light_vectors - c->base.zero_light_vectors;
+        c->base.zero_light_vectors = s.zero_light_vectors;
+        return fail(c, LT_ERR_UNSUPPORTED,
+                    "%llu vertex/point-light pair(s) at zero distance: the reference stops there with 'Found a zero "
+                    "length vector'; that light was left out for that vertex", d);
+    }
     if (s.order_dependent_rows > c->base.order_dependent_rows) {
         unsigned long long d = s.order_dependent_rows - c->base.order_dependent_rows;
         c->base.order_dependent_rows = s.order_dependent_rows;
@@ -572,6 +579,7 @@ int lt_get_counters(lt_ctx *c, lt_counters *out)
     out->order_dependent_rows = s.order_dependent_rows;
     out->unsupported_polys = s.unsupported_polys;
     out->list_overflow = s.list_overflow;
+    out->zero_light_vectors = s.zero_light_vectors;
     return LT_OK;
 }
 
@@ -634,6 +642,66 @@ int lt_transform(lt_ctx *c, const int32_t m[12], const int32_t *d_from, int32_t 
     if (rc) return rc;
     launch_transform(c->stream, m, d_from, d_to, n);
     HIPCHK(c, hipGetLastError());
+    return LT_OK;
+}
+
+int lt_shade_object_dev(lt_ctx *c, const int32_t s9[9], int32_t x, int32_t y, int32_t z, const int32_t *d_verts, int nv,
+                        const int32_t *d_normals, int nn, const int32_t *d_polys, int np, int32_t *d_polyverts,
+                        const int32_t *d_polynormals, int npv, int32_t *d_polyaux, const lt_light *lights, int nlights)
+{
+    if (!c) return LT_ERR_ARG;
+    if (np < 0 || nv < 0 || nn < 0 || npv < 0 || nlights < 0) return fail(c, LT_ERR_ARG, "lt_shade_object: negative count");
+    if (nlights > LT_MAX_LIGHTS) return fail(c, LT_ERR_ARG, "lt_shade_object: %d lights, at most %d", nlights, LT_MAX_LIGHTS);
+    if (np == 0) return LT_OK;
+    if (!s9 || !d_verts || !d_normals || !d_polys || !d_polyverts || !d_polynormals || !d_polyaux || (nlights && !lights))
+        return fail(c, LT_ERR_ARG, "lt_shade_object: NULL array");
+    int rc = use_device(c);
+    if (rc) return rc;
+    static_assert(sizeof(lt_light) == 8 * sizeof(int32_t), "lt_light is eight ints");
+    ShadeArgs a{};
+    for (int i = 0; i < 9; i++) a.s[i] = s9[i];
+    a.x = x; a.y = y; a.z = z;
+    a.verts = d_verts; a.nv = nv; a.normals = d_normals; a.nn = nn;
+    a.polys = d_polys; a.np = np; a.polyverts = d_polyverts; a.polynormals = d_polynormals; a.npv = npv;
+    a.polyaux = d_polyaux;
+    a.nlights = nlights;
+    for (int j = 0; j < nlights; j++) memcpy(a.lights[j], &lights[j], sizeof(lt_light));
+    a.status = c->status;
+    launch_shade(c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return LT_OK;
+}
+
+int lt_shade_object(lt_ctx *c, const int32_t s9[9], int32_t x, int32_t y, int32_t z, const int32_t *verts, int nv,
+                    const int32_t *normals, int nn, const int32_t *polys, int np, int32_t *polyverts,
+                    const int32_t *polynormals, int npv, int32_t *polyaux, const lt_light *lights, int nlights)
+{
+    if (!c) return LT_ERR_ARG;
+    if (np == 0) return LT_OK;
+    if (np < 0 || nv <= 0 || nn <= 0 || npv <= 0 || !verts || !normals || !polys || !polyverts || !polynormals || !polyaux)
+        return fail(c, LT_ERR_ARG, "lt_shade_object: bad argument");
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
+    if ((rc = ensure(c, c->s_verts, (size_t)nv * 16))) return rc;
+    if ((rc = ensure(c, c->s_normals, (size_t)nn * 16))) return rc;
+    if ((rc = ensure(c, c->s_polys, (size_t)np * 16))) return rc;
+    if ((rc = ensure(c, c->s_aux, (size_t)np * 16))) return rc;
+    if ((rc = ensure(c, c->s_pv, (size_t)npv * 24))) return rc;
+    if ((rc = ensure(c, c->s_pn, (size_t)npv * 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_verts.p, verts, (size_t)nv * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_normals.p, normals, (size_t)nn * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_polys.p, polys, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_aux.p, polyaux, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_pv.p, polyverts, (size_t)npv * 24, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_pn.p, polynormals, (size_t)npv * 4, hipMemcpyHostToDevice, c->stream));
+    if ((rc = lt_shade_object_dev(c, s9, x, y, z, (const int *)c->s_verts.p, nv, (const int *)c->s_normals.p, nn,
+                                  (const int *)c->s_polys.p, np, (int *)c->s_pv.p, (const int *)c->s_pn.p, npv,
+                                  (int *)c->s_aux.p, lights, nlights)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(polyverts, c->s_pv.p, (size_t)npv * 24, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(polyaux, c->s_aux.p, (size_t)np * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LT_OK;
 }
 

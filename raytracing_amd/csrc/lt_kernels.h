@@ -54,7 +54,7 @@ struct Status {
     unsigned long long order_dependent_rows;
     unsigned long long unsupported_polys;
     unsigned long long list_overflow;
-    unsigned long long pad;
+    unsigned long long zero_light_vectors;   // shading: (vertex, point light) pairs at zero distance, skipped
 };
 
 struct SetupArgs {
@@ -102,6 +102,23 @@ struct RasterArgs {
     int band_y0, band_y1;          // rows drawn by this context
     Status *status;
 };
+
+// Shading pre-pass (M_shade_polygon_object, EngPoly.cpp:464-493).
+constexpr int MAX_LIGHTS = 16;
+struct ShadeArgs {
+    int s[9];                // self rotation sx1 sy1 sz1 sx2 .. sz3
+    int x, y, z;             // object position
+    const int *verts;  int nv;       // int32[nv][4]
+    const int *normals; int nn;      // int32[nn][4]
+    const int *polys;  int np;       // int32[np][4] = {colour, tex, n_edges, first}
+    int *polyverts;                  // int32[npv][6]: R,G,B written
+    const int *polynormals; int npv; // normal index per record
+    int *polyaux;                    // int32[np][4]: flat r,g,b written
+    int nlights;
+    int lights[MAX_LIGHTS][8];       // {type, px,py,pz,pw, red,green,blue}
+    Status *status;
+};
+void launch_shade(hipStream_t s, const ShadeArgs &a);
 
 void launch_transform(hipStream_t s, const int *m12_dev, const int *from, int *to, int n);
 void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);

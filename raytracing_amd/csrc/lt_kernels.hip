@@ -117,6 +117,148 @@ __global__ void __launch_bounds__(256) transform_kernel(Mat12 M, const int4 *__r
     d[2] = o[2];
 }
 
+// ------------------------------------------------------------------ shading pre-pass
+
+// TI_sqrt, TransLn.cpp:38-51: sixteen result bits, 64-bit accumulators (long is 64 bits in
+// the pinned build).  The bit-by-bit loop yields floor(sqrt(arg)) while that fits sixteen
+// bits and 0xffff beyond; here through the f64 square root with an exact integer fix-up.
+__device__ __forceinline__ unsigned long long ti_sqrt(unsigned long long arg)
+{
+    if (arg >= 0xffffull * 0xffffull) return 0xffffull;
+    unsigned r = (unsigned)__builtin_sqrt((double)arg);          // arg < 2^32: exact in double
+    r = (unsigned long long)r * r > arg ? r - 1u : r;
+    r = (unsigned long long)(r + 1u) * (r + 1u) <= arg ? r + 1u : r;
+    return r;
+}
+
+// (v << 7) / lng of T_unit_vector (TransLn.cpp:186-188), truncating.  |v << 7| < 2^39 and
+// 0 < lng <= 2^20, both exact in double; a quotient that is not an integer is at least
+// 1/lng away from one, far more than the rounding of the division, so the truncated f64
+// quotient is the integer quotient.
+__device__ __forceinline__ int unit_component(int v, long long lng)
+{
+    return (int)(long long)(((double)v * 128.0) / (double)lng);
+}
+
+// T_norm, TransLn.cpp:75-103
+__device__ __forceinline__ long long t_norm(const int (&v)[3])
+{
+    if (v[0] > 0xffff || v[1] > 0xffff || v[2] > 0xffff || v[0] < -0xffff || v[1] < -0xffff || v[2] < -0xffff)
+        return (long long)(ti_sqrt((unsigned long long)((((long long)v[0]) >> 8) * v[0] + (((long long)v[1]) >> 8) * v[1] +
+                                                        (((long long)v[2]) >> 8) * v[2])) << 4);
+    return (long long)ti_sqrt((unsigned long long)((long long)v[0] * v[0] + (long long)v[1] * v[1] + (long long)v[2] * v[2]));
+}
+
+// T_self_rotation, TransBs.cpp:194-214
+__device__ __forceinline__ void self_rotate(const int (&s)[9], const int4 p, int (&o)[3])
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        o[r] = wadd(wadd(wmul(s[3 * r], p.x) >> 15, wmul(s[3 * r + 1], p.y) >> 15), wmul(s[3 * r + 2], p.z) >> 15);
+}
+
+// T_scalar_product, TransLn.cpp:201-208
+__device__ __forceinline__ int scalar_product(const int (&a)[3], const int (&b)[3])
+{
+    return (int)(((long long)a[0] * b[0] + (long long)a[1] * b[1] + (long long)a[2] * b[2]) >> 7);
+}
+
+// M_shade_polygon over M_shade_vertex (EngBase.cpp:220-364): one polygon per lane; every
+// record of the polygon gets its R,G,B from the light list, the polygon its flat
+// illumination (the truncated mean over its n_edges+1 records).  Vertices and normals are
+// moved to world space as they are read (T_self_rotation + T_translation of
+// M_shade_polygon_object, EngPoly.cpp:476-479).
+__global__ void __launch_bounds__(256) shade_kernel(ShadeArgs a)
+{
+    const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    unsigned zero = 0;
+    if (poly < a.np) {
+        const int4 pd = ((const int4 *)a.polys)[poly];
+        const int e = pd.z;
+        const long long first = pd.w;
+        if (e < 0 || first < 0 || first + e + 1 > (long long)a.npv) bad = true;
+        for (int k = 0; !bad && k <= e; k++) {
+            const int vi = a.polyverts[(first + k) * 6], ni = a.polynormals[first + k];
+            if ((unsigned)vi >= (unsigned)a.nv || (unsigned)ni >= (unsigned)a.nn) bad = true;
+        }
+        if (!bad) {
+            int sum[3] = {0, 0, 0};
+            // four records at a time, their loads in flight together (a triangle is one round)
+            for (int k0 = 0; k0 <= e; k0 += 4) {
+                // whole records are read and written back whole: storing only R,G,B would
+                // leave holes in every line, which costs more than the extra bytes
+                int2 ra[4], rc[4];
+                int ni[4];
+                int4 pv[4], pn[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const bool on = k0 + g <= e;
+                    const int2 *rec = (const int2 *)(a.polyverts + (first + k0 + (on ? g : 0)) * 6);
+                    ra[g] = rec[0];
+                    rc[g] = rec[2];
+                    ni[g] = a.polynormals[first + k0 + (on ? g : 0)];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    pv[g] = ((const int4 *)a.verts)[ra[g].x];
+                    pn[g] = ((const int4 *)a.normals)[ni[g]];
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    if (k0 + g > e) continue;
+                    int2 *rec = (int2 *)(a.polyverts + (first + k0 + g) * 6);
+                    int wv[3], wn[3];
+                    self_rotate(a.s, pv[g], wv);
+                    wv[0] = wadd(wv[0], a.x); wv[1] = wadd(wv[1], a.y); wv[2] = wadd(wv[2], a.z);
+                    self_rotate(a.s, pn[g], wn);
+                    int rgb[3] = {0, 0, 0};
+                    for (int j = 0; j < a.nlights; j++) {
+                        const int type = a.lights[j][0];
+                        const int lc[3] = {a.lights[j][5], a.lights[j][6], a.lights[j][7]};
+                        const int lp[3] = {a.lights[j][1], a.lights[j][2], a.lights[j][3]};
+                        int prd = -1;
+                        if (type == 1) {                                   // M_AMBIENT
+#pragma unroll
+                            for (int q = 0; q < 3; q++) rgb[q] = wadd(rgb[q], lc[q]);
+                        } else if (type == 2) {                            // M_POINT: T_unit_vector, TransLn.cpp:175-190
+                            const int v[3] = {wsub(lp[0], wv[0]), wsub(lp[1], wv[1]), wsub(lp[2], wv[2])};
+                            const long long lng = t_norm(v);
+                            if (lng == 0) zero++;
+                            else {
+                                const int lv[3] = {unit_component(v[0], lng), unit_component(v[1], lng), unit_component(v[2], lng)};
+                                prd = scalar_product(lv, wn);
+                            }
+                        } else if (type == 4) {                            // M_DIRECT
+                            prd = (int)(0u - (unsigned)scalar_product(lp, wn));
+                        }
+                        if (type != 1 && prd >= 0) {
+#pragma unroll
+                            for (int q = 0; q < 3; q++) rgb[q] = wadd(rgb[q], wmul(prd, lc[q]) >> 7);
+                        }
+                    }
+                    rec[0] = make_int2(ra[g].x, rgb[0]);
+                    rec[1] = make_int2(rgb[1], rgb[2]);
+                    rec[2] = rc[g];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) sum[q] = wadd(sum[q], rgb[q]);
+                }
+            }
+            int4 *ax = (int4 *)a.polyaux + poly;
+            const double rn = drcp(e + 1);
+            *ax = make_int4(tdivr(sum[0], rn), tdivr(sum[1], rn), tdivr(sum[2], rn), ax->w);      // whole 16 bytes, 4th kept
+        }
+    }
+    // counters: one atomic per wave
+    Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
+    const unsigned long long bm = __ballot(bad);
+    if (bm && (threadIdx.x & 63) == (__ffsll((long long)bm) - 1)) atomicAdd(&st->overflow_polys, (unsigned long long)__popcll(bm));
+    unsigned long long zs = zero;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) zs += __shfl_down(zs, d);
+    if ((threadIdx.x & 63) == 0 && zs) atomicAdd(&st->zero_light_vectors, zs);
+}
+
 // Lanes of one wave exchange data through LDS: the wave's LDS operations complete in issue
 // order, so all this needs is that the compiler keeps the order (a release fence limited
 // to LDS: a full fence would also wait for every global access in flight, prefetches
@@ -1607,6 +1749,12 @@ void launch_transform(hipStream_t s, const int *m12, const int *from, int *to, i
     Mat12 M;
     for (int i = 0; i < 12; i++) M.m[i] = m12[i];
     hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, M, (const int4 *)from, to, n);
+}
+
+void launch_shade(hipStream_t s, const ShadeArgs &a)
+{
+    if (a.np <= 0) return;
+    hipLaunchKernelGGL(shade_kernel, dim3((a.np + 255) / 256), dim3(256), 0, s, a);
 }
 
 void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)

@@ -138,6 +138,27 @@ class Context:
         m = _i32(m12)
         self._chk(self.L.lt_transform(self.h_ctx, _p(m), _dp(d_from), _dp(d_to), d_from.shape[0]))
 
+    def shade_object_dev(self, s9, pos, d_verts, d_normals, d_polys, d_polyverts, d_polynormals, d_polyaux, lights):
+        """M_shade_polygon_object on device arrays: R,G,B of d_polyverts and the flat r,g,b of
+        d_polyaux are overwritten.  lights: int32[n][8] = {type, px, py, pz, pw, red, green, blue}."""
+        s = _i32(s9)
+        li = _i32(lights).reshape(-1, 8)
+        self._chk(self.L.lt_shade_object_dev(self.h_ctx, _p(s), int(pos[0]), int(pos[1]), int(pos[2]),
+                                             _dp(d_verts), d_verts.shape[0], _dp(d_normals), d_normals.shape[0],
+                                             _dp(d_polys), d_polys.shape[0], _dp(d_polyverts), _dp(d_polynormals),
+                                             d_polyverts.shape[0], _dp(d_polyaux), _p(li), li.shape[0]))
+
+    def shade_object(self, s9, pos, verts, normals, polys, polyverts, polynormals, polyaux, lights):
+        """host arrays -> (polyverts with R,G,B, polyaux with flat r,g,b)"""
+        s, li = _i32(s9), _i32(lights).reshape(-1, 8)
+        v, n, po = _i32(verts).reshape(-1, 4), _i32(normals).reshape(-1, 4), _i32(polys).reshape(-1, 4)
+        pv, pn = _i32(polyverts).reshape(-1, 6).copy(), _i32(polynormals).reshape(-1)
+        pa = np.zeros((po.shape[0], 4), np.int32) if polyaux is None else _i32(polyaux).reshape(-1, 4).copy()
+        self._chk(self.L.lt_shade_object(self.h_ctx, _p(s), int(pos[0]), int(pos[1]), int(pos[2]), _p(v), v.shape[0],
+                                         _p(n), n.shape[0], _p(po), po.shape[0], _p(pv), _p(pn), pv.shape[0], _p(pa),
+                                         _p(li), li.shape[0]))
+        return pv, pa
+
     def submit_object(self, verts, polys, polyverts, render_type, log_focus, polyaux=None, matrix=None,
                       force_linear=0, max_edges=0):
         m = _i32(IDENTITY if matrix is None else matrix)

@@ -331,6 +331,45 @@ void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *
     if (poly->m_no_edges > q_max_edges) q_max_edges = poly->m_no_edges;
 }
 
+void M_shade_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam,
+                            int no_lights, struct M_light **lights)
+{
+    need_ctx();
+    if (object->m_no_vertices > M_MAX_OBJECT_VERTICES || object->m_no_normals > M_MAX_OBJECT_VERTICES)
+        HW_error((char *)"(Engine) Can't handle this many vertices or normals in polygons.");    // EngPoly.cpp:481-484
+    if (no_lights > LT_MAX_LIGHTS) HW_error((char *)"(Engine) more lights than the GPU path takes.\n");
+    T_set_self_rotation((unsigned char)alp, (unsigned char)bet, (unsigned char)gam);
+    std::vector<int32_t> polys, aux, pv, pn;
+    for (int i = 0; i < object->m_no_polygons; i++) {
+        const M_polygon *p = object->m_polygons[i];
+        const int32_t hd[4] = {p->m_colour, -1, p->m_no_edges, (int32_t)(pv.size() / 6)};
+        polys.insert(polys.end(), hd, hd + 4);
+        const int32_t ax[4] = {p->m_red, p->m_green, p->m_blue, 0};
+        aux.insert(aux.end(), ax, ax + 4);
+        pv.insert(pv.end(), p->m_vertices, p->m_vertices + (size_t)(p->m_no_edges + 1) * M_LNG_POLYGON_VERTEX);
+        pn.insert(pn.end(), p->m_normals, p->m_normals + (p->m_no_edges + 1));
+    }
+    std::vector<lt_light> ls((size_t)(no_lights > 0 ? no_lights : 0));
+    for (int j = 0; j < no_lights; j++) {
+        ls[j].type = lights[j]->m_type;
+        for (int k = 0; k < 4; k++) ls[j].param[k] = lights[j]->m_parameter[k];
+        ls[j].red = lights[j]->m_red; ls[j].green = lights[j]->m_green; ls[j].blue = lights[j]->m_blue;
+    }
+    chk(lt_shade_object(g_ctx, Ts, x, y, z, object->m_vertices, object->m_no_vertices, object->m_normals,
+                        object->m_no_normals, polys.data(), object->m_no_polygons, pv.data(), pn.data(),
+                        (int)(pv.size() / 6), aux.data(), ls.data(), no_lights));
+    chk(lt_flush(g_ctx));          // a point light on a vertex stops the reference; HW_error says so here
+    size_t r = 0;
+    for (int i = 0; i < object->m_no_polygons; i++) {
+        M_polygon *p = object->m_polygons[i];
+        for (int k = 0; k <= p->m_no_edges; k++, r++) {
+            int *rec = p->m_vertices + k * M_LNG_POLYGON_VERTEX;
+            rec[1] = pv[r * 6 + 1]; rec[2] = pv[r * 6 + 2]; rec[3] = pv[r * 6 + 3];
+        }
+        p->m_red = aux[(size_t)i * 4]; p->m_green = aux[(size_t)i * 4 + 1]; p->m_blue = aux[(size_t)i * 4 + 2];
+    }
+}
+
 void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam)
 {
     need_ctx();

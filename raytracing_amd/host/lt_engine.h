@@ -106,6 +106,21 @@ struct M_polygon_object {
     int *m_normals;
 };
 
+// Engine.h:112-130 (_RGB_)
+#define M_AMBIENT 0x1
+#define M_POINT   0x2
+#define M_DIRECT  0x4
+struct M_light {
+    int m_type;
+    int m_parameter[4];
+    int m_red, m_green, m_blue;
+};
+
+// EngPoly.cpp:464-493: every polygon's vertex records receive their R,G,B and the polygon
+// its flat m_red/m_green/m_blue, computed on the GPU and written back before the call returns.
+void M_shade_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam,
+                            int no_lights, struct M_light **lights);
+
 void M_init_rendering(int type);
 void M_set_camera(unsigned char alp, unsigned char bet, unsigned char gam, int x, int y, int z, int log_focus);
 void M_render_polygon(struct M_polygon *polygon, int *vertices, int *colours, int *textures);

@@ -58,6 +58,34 @@ void lte_render_object(int *verts, int nv, const int *polys, const int *aux, int
     M_render_polygon_object(&obj, x, y, z, alp, bet, gam);
 }
 
+// M_shade_polygon_object on one object; polyverts R,G,B and aux r,g,b are written back
+void lte_shade_object(int *verts, int nv, int *normals, int nn, const int *polys, int *aux, int *pv, int *pn, int np,
+                      int x, int y, int z, int alp, int bet, int gam, const int *lights, int nl)
+{
+    std::vector<M_polygon> store(np);
+    std::vector<M_polygon *> ptrs(np);
+    for (int i = 0; i < np; i++) {
+        fill(&store[i], g_texs, polys, aux, pv, i);
+        store[i].m_normals = pn + polys[i * 4 + 3];
+        ptrs[i] = &store[i];
+    }
+    std::vector<M_light> ls(nl);
+    std::vector<M_light *> lp(nl);
+    for (int j = 0; j < nl; j++) {
+        ls[j].m_type = lights[j * 8];
+        for (int k = 0; k < 4; k++) ls[j].m_parameter[k] = lights[j * 8 + 1 + k];
+        ls[j].m_red = lights[j * 8 + 5]; ls[j].m_green = lights[j * 8 + 6]; ls[j].m_blue = lights[j * 8 + 7];
+        lp[j] = &ls[j];
+    }
+    M_polygon_object obj;
+    obj.m_type = M_POLYGON_OBJECT; obj.m_order = nullptr;
+    obj.m_no_polygons = np; obj.m_polygons = ptrs.data();
+    obj.m_no_vertices = nv; obj.m_vertices = verts;
+    obj.m_no_normals = nn; obj.m_normals = normals;
+    M_shade_polygon_object(&obj, x, y, z, alp, bet, gam, nl, lp.data());
+    for (int i = 0; i < np; i++) { aux[i * 4] = store[i].m_red; aux[i * 4 + 1] = store[i].m_green; aux[i * 4 + 2] = store[i].m_blue; }
+}
+
 // the transform, then one M_render_polygon call per polygon (as EngPoly.cpp:512-523 does)
 void lte_render_polys_one_by_one(int *verts, int nv, const int *polys, const int *aux, int *pv, int np, int type,
                                  int log_focus, int x, int y, int z, int alp, int bet, int gam)

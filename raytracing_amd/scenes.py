@@ -305,3 +305,37 @@ def frame_digest(a: np.ndarray) -> str:
     """Checksum of an int32 frame (little-endian bytes): blake2b-64, hex."""
     import hashlib
     return hashlib.blake2b(np.ascontiguousarray(a, dtype="<i4").tobytes(), digest_size=8).hexdigest()
+
+
+def gen_shading_case(n_polys: int, seed: int, n_verts: int = 0, n_normals: int = 0, extent: int = 2000,
+                     far_light: bool = True):
+    """Input of the shading pre-pass (M_shade_polygon_object): random polygons of 3..5 edges
+    over shared vertices, unit normals scaled by 1<<7, one ambient, two point and one
+    directional light (a far point light exercises the long-vector branch of T_norm).
+    -> dict(verts, normals, polys, polyverts, polynormals, lights)"""
+    rng = Rng(seed)
+    nv = n_verts or max(8, n_polys * 2)
+    nn = n_normals or max(8, n_polys)
+    verts = np.zeros((nv, 4), np.int32)
+    verts[:, :3] = rng.ints(-extent, extent, nv * 3).reshape(-1, 3)
+    raw = rng.ints(-100, 100, nn * 3).reshape(-1, 3).astype(np.float64) + 0.5
+    normals = np.zeros((nn, 4), np.int32)
+    normals[:, :3] = np.round(raw / np.linalg.norm(raw, axis=1)[:, None] * 128).astype(np.int32)
+    e = rng.ints(3, 5, n_polys).astype(np.int64)
+    first = np.concatenate([[0], np.cumsum(e + 1)[:-1]])
+    npv = int((e + 1).sum())
+    pv = np.zeros((npv, 6), np.int32)
+    pv[:, 0] = rng.ints(0, nv - 1, npv)
+    pv[:, 1:4] = -1                                   # overwritten by the pre-pass
+    pv[:, 4:6] = rng.ints(0, 1023, npv * 2).reshape(-1, 2)
+    pn = rng.ints(0, nn - 1, npv).astype(np.int32)
+    polys = np.zeros((n_polys, 4), np.int32)
+    polys[:, 0] = 0x00FFFFFF
+    polys[:, 1] = -1
+    polys[:, 2] = e
+    polys[:, 3] = first
+    lights = np.array([[1, 0, 0, 0, 0, 20, 30, 40],
+                       [2, 500, -300, -800, 0, 200, 180, 160],
+                       [4, 40, -90, 80, 0, 90, 100, 110],
+                       [2, 70000 if far_light else 900, 3, 9, 0, 255, 255, 255]], np.int32)
+    return dict(verts=verts, normals=normals, polys=polys, polyverts=pv, polynormals=pn, lights=lights)

@@ -58,3 +58,9 @@ def make_matrix(cam=(0, 0, 0, 0, 0, 0), obj=(0, 0, 0, 0, 0, 0)):
               _w(_fx(s[2], wx) + _fx(s[5], wy) + _fx(s[8], wz)),
               _w(_fx(ax, wx) + _fx(ay, wy) + _fx(az, wz))]
     return np.array(m, dtype=np.int32)
+
+
+def self_matrix(alp, bet, gam):
+    """T_set_self_rotation -> int32[9] = sx1 sy1 sz1 sx2 sy2 sz2 sx3 sy3 sz3, the matrix
+    lt_shade_object takes (M_shade_polygon_object rotates vertices and normals by it)."""
+    return np.array(self_rotation(alp, bet, gam), dtype=np.int32)

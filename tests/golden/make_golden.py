@@ -303,7 +303,30 @@ def c1_golden():
     return out
 
 
+def shade_kats():
+    """Shading pre-pass vectors: the reference's M_shade_polygon_object on generated cases."""
+    r = R.Ref(160, 120)
+    out = {}
+    cases = [(120, 7001, (0, 0, 0), (0, 0, 0), True), (200, 7002, (13, 200, 77), (100, -50, 400), True),
+             (90, 7003, (250, 3, 128), (-2000, 900, 15), False)]
+    for k, (n, seed, ang, pos, far) in enumerate(cases):
+        c = S.gen_shading_case(n, seed, far_light=far)
+        pv, pa = r.shade_object(c["verts"], c["normals"], c["polys"], c["polyverts"], c["polynormals"], None, pos, ang,
+                                c["lights"])
+        out[f"np_{k}"] = n
+        out[f"seed_{k}"] = seed
+        out[f"ang_{k}"] = np.array(ang, np.int32)
+        out[f"pos_{k}"] = np.array(pos, np.int32)
+        out[f"far_{k}"] = far
+        out[f"s9_{k}"] = r.self_matrix(*ang)
+        out[f"rgb_{k}"] = pv[:, 1:4].copy()
+        out[f"flat_{k}"] = pa[:, :3].copy()
+    out["n_cases"] = len(cases)
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "shade_kats.npz"), **shade_kats())
     if not os.path.isdir(REFDIR):
         raise SystemExit("needs /root/reference (run in the build container)")
     np.savez_compressed(os.path.join(HERE, "stage_kats.npz"), **stage_kats())

@@ -80,3 +80,22 @@ def test_render_polygon_one_by_one_and_screen_polys(eng):
         eng.lte_g_polygon(4, _p(tt), e, col, 0, 0, 0, 0)
     c, z = _frame(eng)
     assert np.array_equal(z, orc.zbuf()) and np.array_equal(c, orc.cbuf())
+
+
+def test_shade_polygon_object(eng):
+    """M_shade_polygon_object through the mirror: records and flat colours written back
+    into the caller's polygons, equal to the restatement's"""
+    import oracle.port as P
+    case = S.gen_shading_case(200, 77, n_verts=600, n_normals=300)
+    ang, pos = (40, 7, 211), (120, -60, 900)
+    want_pv, want_pa, skipped, bad = P.shade_polys(P.self_matrix(*ang), pos, case["verts"], case["normals"],
+                                                   case["polys"], case["polyverts"], case["polynormals"], None,
+                                                   case["lights"])
+    assert skipped == 0 and bad == 0
+    v, n, po = case["verts"].copy(), case["normals"].copy(), case["polys"].copy()
+    pv, pn = case["polyverts"].copy(), case["polynormals"].copy()
+    aux = np.zeros((po.shape[0], 4), np.int32)
+    li = case["lights"].copy()
+    eng.lte_shade_object(_p(v), v.shape[0], _p(n), n.shape[0], _p(po), _p(aux), _p(pv), _p(pn), po.shape[0],
+                         *pos, *ang, _p(li), li.shape[0])
+    assert np.array_equal(pv, want_pv) and np.array_equal(aux[:, :3], want_pa[:, :3])
