@@ -1209,7 +1209,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(unsigned *__restrict__ count
 __device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &xa, int &ib, int &xb)
 {
     // Branch-free: both the y-major and the x-major forms divide by 2*|dy| (2L for a
-    // y-major edge, 2s for an x-major one), so one reciprocal serves the three quotients
+    // y-major edge, 2s for an x-major one), so one reciprocal serves both quotients
     // and selects pick the form that applies.
     const int x1 = xy1 & 0xffff, y1 = (xy1 >> 16) & 0xffff, x2 = xy2 & 0xffff, y2 = (xy2 >> 16) & 0xffff;
     const int dx = x2 - x1, dy = y2 - y1;
@@ -1221,13 +1221,14 @@ __device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &
     const float rd = __builtin_amdgcn_rcpf((float)d2);
     const int a2j = __mul24(2 * adx, j);
     const int nB = a2j - adx + 2 * ady - 1;
-    const int h = udiv_r(a2j + ady, d2, rd);                   // y-major: diagonal steps before point j
-    const int qB = udiv_r(nB, d2, rd);                          // x-major: first point of row j (j >= 1)
-    const int qC = udiv_r(nB + 2 * adx, d2, rd);                // x-major: first point of row j+1
-    const int ilo = j == 0 ? 0 : qB;
+    // first quotient: diagonal steps before point j (y-major) or first point of row j
+    // (x-major, j >= 1); both are 0 for j = 0.  Second: first point of row j+1 (x-major).
+    const int q1 = udiv_r(xmaj ? nB : a2j + ady, d2, rd);
+    const int qC = udiv_r(nB + 2 * adx, d2, rd);
+    const int olo = j == 0 ? 0 : q1;                            // x distance of the row's first point from x1
     const int ihi = j == ady ? adx : qC - 1;
-    const int lo = xmaj ? ilo : j, hi = xmaj ? ihi : j;         // point indices of the row's two end points
-    const int olo = xmaj ? ilo : h, ohi = xmaj ? ihi : h;       // their x distances from x1
+    const int ohi = xmaj ? ihi : olo;
+    const int lo = xmaj ? olo : j, hi = xmaj ? ihi : j;         // point indices of the row's two end points
     const bool fwd = dx >= 0;
     ia = fwd ? lo : hi;
     ib = fwd ? hi : lo;
