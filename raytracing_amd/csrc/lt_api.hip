@@ -222,7 +222,8 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         if (w.in_use) HIPCHK(c, hipStreamWaitEvent(gs, w.raster_done, 0));
     }
     if ((rc = ensure(c, w.hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
-    if ((rc = ensure(c, w.edges, (size_t)np * emax * edge_ints(na) * sizeof(int)))) return rc;
+    // the fill fetches edges 0..2 of every listed polygon without waiting for its header: at least three planes
+    if ((rc = ensure(c, w.edges, (size_t)np * (emax < 3 ? 3 : emax) * edge_ints(na) * sizeof(int)))) return rc;
     if ((rc = ensure(c, w.list, (size_t)capacity * sizeof(unsigned)))) return rc;
     const bool want_prp = !screen && dim == 8;
     if (want_prp && (rc = ensure(c, w.prp, (size_t)np * PRP_INTS * sizeof(int)))) return rc;
