@@ -104,6 +104,25 @@ def cpu_baseline(sc, passes, want_frame=True):
     return base, c, z
 
 
+def cpu_all_cores(workload, tris, cores, passes=3):
+    """The same frame on `cores` host cores at once: independent processes (the reference is
+    not re-entrant), started before this process touches the GPU.  Returns the dict or None."""
+    import subprocess
+    start_at = time.time() + 12.0 + tris / 2.5e5           # scene generation and library loading come first
+    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), workload, str(tris), str(passes), str(start_at)]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(cores)]
+    rate, kinds = 0.0, set()
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        if p.returncode != 0 or not out.strip():
+            return None
+        secs, kind = out.split()
+        rate += tris * passes / float(secs)
+        kinds.add(kind)
+    return {"value": round(rate / 1e6, 3), "unit": "Mtris/s", "cores": cores, "kind": kinds.pop() if len(kinds) == 1 else "mixed",
+            "sample": f"{cores} processes, each {passes} pass(es) over the full {tris}-triangle frame, timed loops started together"}
+
+
 def bench_shade(args, rank, local_rank, world):
     """--workload shade: the shading pre-pass (M_shade_polygon_object) alone, one call per
     step over `--tris` triangles (four vertex records each), four lights, arrays in HBM."""
@@ -183,6 +202,8 @@ def main():
     ap.add_argument("--host-arrays", action="store_true",
                     help="submit from host memory (the boundary's host-pointer entry point): PCIe-inclusive rate, "
                          "reported for reference, never the headline value")
+    ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1),
+                    help="processes of the all-cores CPU baseline (0 = skip it)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
     args = ap.parse_args()
 
@@ -191,6 +212,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # the all-cores CPU baseline starts child processes: before this process touches the GPU
+    all_cores = None
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_cores > 1 and args.workload.startswith("c2"):
+        all_cores = cpu_all_cores(args.workload, args.tris, args.cpu_cores)
 
     import torch
     import torch.distributed as dist
@@ -324,6 +350,8 @@ def main():
             base, oc, oz = cpu_baseline(sc, passes=2 if sc.n_polys <= 2_000_000 else 1)
             c, z = ctx.readback()
             out["cpu_baseline"] = base
+            if all_cores:
+                out["cpu_baseline_all_cores"] = all_cores
             out["frame_matches_cpu"] = bool(np.array_equal(c, oc) and np.array_equal(z, oz))
         print(json.dumps(out), flush=True)
 
