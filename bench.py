@@ -72,6 +72,23 @@ def measured_traffic(workload, tris, stage):
     return None, None
 
 
+def valu_roofline(workload, tris, stage, kernel_ms):
+    """Second ceiling for the fill, which is bound by VALU issue: wave-instructions per launch
+    (SQ_INSTS_VALU of the committed counter pass) over the kernel's measured duration, against
+    1024 SIMDs issuing one wave-instruction per 4 cycles at the 2.4 GHz peak clock."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_c2small.json")
+    if workload != "c2-small" or tris != 1_000_000 or not os.path.exists(path) or kernel_ms <= 0:
+        return None
+    for name, ctrs in json.load(open(path)).items():
+        if STAGE_KERNEL.get(stage, "?") in name and "SQ_INSTS_VALU" in ctrs:
+            insts = ctrs["SQ_INSTS_VALU"]["mean_per_launch"]
+            peak = 1024 * 2.4e9 / 4 / 1e9
+            ach = insts / (kernel_ms * 1e-3) / 1e9
+            return {"bound": "valu", "kernel": stage, "achieved": round(ach, 1), "peak": round(peak, 1),
+                    "unit": "G wave-instructions/s", "frac": round(ach / peak, 4), "wave_instructions_per_launch": int(insts)}
+    return None
+
+
 def cpu_baseline(sc, passes, want_frame=True):
     """Time the CPU checker on the same scene; returns (dict, colour, depth)."""
     import oracle.port as P
@@ -204,11 +221,13 @@ def main():
                          "reported for reference, never the headline value")
     ap.add_argument("--cpu-cores", type=int, default=min(16, os.cpu_count() or 1),
                     help="processes of the all-cores CPU baseline (0 = skip it)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if "--share-gpu" in sys.argv else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -224,7 +243,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     if args.workload == "shade":
         bench_shade(args, rank, local_rank, world)
@@ -346,6 +368,9 @@ def main():
                          "algorithmic_bytes_per_launch": frame_bytes,
                          "whole_step_frac": round(frame_bytes / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
         }
+        vr = valu_roofline(args.workload, sc.n_polys, dom, dom_ms)
+        if vr:
+            out["roofline_valu"] = vr
         if not args.no_cpu:
             base, oc, oz = cpu_baseline(sc, passes=2 if sc.n_polys <= 2_000_000 else 1)
             c, z = ctx.readback()
