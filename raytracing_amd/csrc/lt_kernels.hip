@@ -1145,46 +1145,70 @@ __global__ void __launch_bounds__(256) scatter_direct_kernel(const PrimHdr *__re
             }
 }
 
-// Exclusive prefix sum of the per-tile reference counts (one workgroup; the tile count
-// is at most a few hundred thousand).  Also zeroes the scatter cursors, and leaves the
-// counts and the set-up sub-queue counters at zero for the next batch that uses these
-// arrays (they are zero when allocated), so no batch needs a memset.
+// Exclusive prefix sum of the per-tile reference counts, one workgroup of 1024 threads.
+// Tiles are taken 1024 at a time, coalesced.  Pass 1 leaves every wave's sum of every
+// step in LDS (no barrier inside the loop, so the loads of all steps are in flight
+// together); the wave sums are scanned; pass 2 reads the counts again (from L2) and writes
+// the offsets.  Also zeroes the scatter cursors, and leaves the counts and the set-up
+// sub-queue counters at zero for the next batch that uses these arrays (they are zero
+// when allocated), so no batch needs a memset.
+constexpr int SCAN_MAX_STEPS = 128;        // 131072 tiles: the largest screen (16384 x 16384)
 __global__ void __launch_bounds__(1024) scan_kernel(unsigned *__restrict__ count, unsigned *__restrict__ offset,
                                                     unsigned *__restrict__ cursor, int n,
                                                     unsigned long long capacity, unsigned *__restrict__ queue_count,
                                                     Status *status)
 {
-    __shared__ unsigned wsum[16];
-    __shared__ unsigned carry_s;
+    __shared__ unsigned wsum[SCAN_MAX_STEPS * 16];
+    __shared__ unsigned tsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if (t == 0) carry_s = 0;
+    const int steps = (n + 1023) / 1024;
+    for (int st = 0; st < steps; st++) {
+        const int i = st * 1024 + t;
+        unsigned s = i < n ? count[i] : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+        if (lane == 0) wsum[st * 16 + w] = s;
+    }
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        int i = base + t;
-        unsigned v = i < n ? count[i] : 0u;
-        if (i < n) count[i] = 0u;
+    // exclusive scan of the steps*16 wave sums: two per thread
+    {
+        const int m = steps * 16;
+        const unsigned a0 = 2 * t < m ? wsum[2 * t] : 0u, a1 = 2 * t + 1 < m ? wsum[2 * t + 1] : 0u;
+        unsigned s = a0 + a1;
+        const unsigned mine = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(s, d);
+            if (lane >= d) s += o;
+        }
+        if (lane == 63) tsum[w] = s;
+        __syncthreads();
+        unsigned pre = 0;
+        for (int k = 0; k < w; k++) pre += tsum[k];
+        const unsigned ex = pre + s - mine;
+        if (2 * t < m) wsum[2 * t] = ex;
+        if (2 * t + 1 < m) wsum[2 * t + 1] = ex + a0;
+    }
+    __syncthreads();
+    unsigned total = 0;
+    for (int k = 0; k < 16; k++) total += tsum[k];
+    for (int st = 0; st < steps; st++) {
+        const int i = st * 1024 + t;
+        const unsigned v = i < n ? count[i] : 0u;
         unsigned s = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            unsigned o = __shfl_up(s, d);
+            const unsigned o = __shfl_up(s, d);
             if (lane >= d) s += o;
         }
-        if (lane == 63) wsum[w] = s;
-        __syncthreads();
-        unsigned pre = 0;
-        for (int k = 0; k < w; k++) pre += wsum[k];
-        unsigned carry = carry_s;
-        if (i < n) { offset[i] = carry + pre + s - v; cursor[i] = 0; }
-        __syncthreads();
-        if (t == 1023) carry_s = carry + pre + s;
-        __syncthreads();
+        if (i < n) { offset[i] = wsum[st * 16 + w] + s - v; cursor[i] = 0u; count[i] = 0u; }
     }
     if (queue_count && t < QUEUES) queue_count[t * QUEUE_COUNT_STRIDE] = 0u;
     if (t == 0) {
-        offset[n] = carry_s;
-        atomicAdd(&status->tile_refs, (unsigned long long)carry_s);
-        if ((unsigned long long)carry_s > capacity)
-            atomicAdd(&status->list_overflow, (unsigned long long)carry_s - capacity);
+        offset[n] = total;
+        atomicAdd(&status->tile_refs, (unsigned long long)total);
+        if ((unsigned long long)total > capacity)
+            atomicAdd(&status->list_overflow, (unsigned long long)total - capacity);
     }
 }
 
