@@ -352,7 +352,7 @@ def main():
             "data": "synthetic" + (", submitted from host memory every frame (PCIe-inclusive)" if args.host_arrays else ""),
             "config": {"workload": f"{args.workload}: {sc.n_polys} Gouraud Z-buffered triangles per frame at "
                                    f"{sc.width}x{sc.height}, one frame per step per GPU"
-                       if args.workload.startswith("c2") else
+                       if sc.render_type == 4 else
                        f"{args.workload}: {sc.n_polys} textured triangles per frame at {sc.width}x{sc.height}",
                        "parallelism": (f"sort-first row bands x{world}, bands gathered to rank 0" if bands
                                        else f"frame-parallel x{world}"), "tile": f"{64}x{32}"},
