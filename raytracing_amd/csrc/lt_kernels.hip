@@ -1308,9 +1308,11 @@ __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, 
     return true;
 }
 
-__device__ __forceinline__ unsigned long long depth_key(int z, unsigned id)
+// (depth, draw index) packed for a signed 64-bit minimum: the depth is the signed high
+// word, and between equal depths the low word compares as an unsigned magnitude.
+__device__ __forceinline__ long long depth_key(int z, unsigned id)
 {
-    return ((unsigned long long)((unsigned)z ^ 0x80000000u) << 32) | id;
+    return (long long)(((unsigned long long)(unsigned)z << 32) | id);
 }
 
 // Depth span of one row from up to three edges held in registers (the depth pass of
@@ -1533,7 +1535,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     // rows are KW keys apart: with a stride of exactly TW every row would start in the same
     // LDS bank, and the lanes of the depth pass walk different rows at similar columns
     constexpr int KW = TW + 1;
-    __shared__ unsigned long long keys[TH * KW];
+    __shared__ long long keys[TH * KW];
     __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 lanes x {edge0, edge1, edge2, {poly, ne, r0, offset}}
 
     const int t = threadIdx.x, lane = t & 63;
@@ -1659,7 +1661,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                         const int xa = max(beg, tx0), xb = min(end, tx0 + TW - 1);
                         if (xa <= xb) {
                             frags += (unsigned long long)(xb - xa + 1);
-                            unsigned long long *krow = keys + (y - ty0) * KW - tx0;
+                            long long *krow = keys + (y - ty0) * KW - tx0;
                             int z = wadd(zs, wmul(xa - beg, zi));
                             int x = xa;
                             for (; x + 3 <= xb; x += 4) {           // four pixels per trip: constant offsets, one loop test
@@ -1688,13 +1690,13 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     unsigned long long qrows = 0;
     constexpr int CG = 4;
     for (int p0 = t; p0 < TW * TH; p0 += RASTER_THREADS * CG) {
-        unsigned long long kk[CG];
+        long long kk[CG];
         int4 hh[CG];
         int2 xy[CG][3];
 #pragma unroll
         for (int g = 0; g < CG; g++) {
             const int p = p0 + g * RASTER_THREADS;
-            kk[g] = p < TW * TH ? keys[(p / TW) * KW + p % TW] : 0ull;
+            kk[g] = p < TW * TH ? keys[(p / TW) * KW + p % TW] : 0ll;
             hh[g] = zero4;
 #pragma unroll
             for (int e = 0; e < 3; e++) xy[g][e] = make_int2(0, 0);
@@ -1717,7 +1719,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
             if (p >= TW * TH) continue;
             const int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
             if (gx >= a.W || gy >= a.H) continue;
-            const unsigned long long k = kk[g];
+            const long long k = kk[g];
             const unsigned id = (unsigned)k;
             const size_t gi = (size_t)gy * a.W + gx;
             if (id == 0u) {
@@ -1739,7 +1741,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                 if (NA == 6 && kind >= KIND_TEX_LIN && ((I[1 % NA] | I[2 % NA] | I[3 % NA]) != 0)) qrows++;
                 c = pixel_colour<NA>(a, h, poly, gx, gy, beg, end, S, I, gx - beg);
             }
-            a.zbuf[gi] = (int)((unsigned)(k >> 32) ^ 0x80000000u);
+            a.zbuf[gi] = (int)(k >> 32);
             a.cbuf[gi] = c;
         }
     }
