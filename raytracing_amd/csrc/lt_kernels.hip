@@ -1528,6 +1528,8 @@ __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
 // Pixels that no polygon of this batch won keep what the frame held (or the clear
 // colour).  The frame is read (depth only) at most once per tile and written once.
 
+constexpr unsigned HIZ_MIN_REFS = 4 * RASTER_THREADS;      // tile list length from which the coarse depth test is used
+
 template <int NA>
 __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
 {
@@ -1536,6 +1538,13 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     // LDS bank, and the lanes of the depth pass walk different rows at similar columns
     constexpr int KW = TW + 1;
     __shared__ long long keys[TH * KW];
+    // Coarse depth test for tiles with long lists (deep overdraw): the largest depth held in
+    // each run of 8 pixels of a tile row, refreshed from the keys at the start of every round.
+    // Keys only ever decrease, so a stale entry is merely conservative: a piece of a span
+    // whose smallest depth is greater than the entry cannot lower any key there and is
+    // skipped without touching the keys.  Its fragments are counted all the same.
+    static_assert(RASTER_THREADS == TH * (TW / 8), "one thread refreshes one 8-pixel run");
+    __shared__ int zmax[TH * (TW / 8)];
     __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 lanes x {edge0, edge1, edge2, {poly, ne, r0, offset}}
 
     const int t = threadIdx.x, lane = t & 63;
@@ -1559,6 +1568,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     __syncthreads();
 
     unsigned long long frags = 0;
+    const bool hiz = lcnt >= HIZ_MIN_REFS;
 
     // ---- depth pass.  Loads are software-pipelined: while a round's rows are drawn, the
     // header and the depth pieces of the three first edge records of the next round's
@@ -1583,6 +1593,13 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         e2_c = *edge_piece(a.edges, a.np, ESZ / 4, 2, 0, poly_c);
     }
     for (unsigned rd = 0; rd < rounds; rd++) {
+        if (hiz) {
+            const long long *k8 = keys + (t >> 3) * KW + (t & 7) * 8;
+            int m = (int)(k8[0] >> 32);
+#pragma unroll
+            for (int q = 1; q < 8; q++) m = max(m, (int)(k8[q] >> 32));
+            zmax[t] = m;
+        }
         int4 h_n = zero4, e0_n = zero4, e1_n = zero4, e2_n = zero4;
         if (poly_n >= 0) {
             h_n = ((const int4 *)a.hdr)[poly_n];
@@ -1664,6 +1681,20 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
                             long long *krow = keys + (y - ty0) * KW - tx0;
                             int z = wadd(zs, wmul(xa - beg, zi));
                             int x = xa;
+                            // the coarse test needs the depth to run monotonically along the span: no 32-bit wrap
+                            const long long za = (long long)zs + (long long)(xa - beg) * zi, zb = (long long)zs + (long long)(xb - beg) * zi;
+                            if (hiz && za == (int)za && zb == (int)zb) {
+                                const int *zrow = zmax + (y - ty0) * (TW / 8);
+                                while (x <= xb) {
+                                    const int bend = min(xb, x | 7);
+                                    const int z1 = wadd(z, wmul(bend - x, zi));
+                                    if ((min(z, z1) >> 16) > zrow[(x - tx0) >> 3]) { z = wadd(z1, zi); x = bend + 1; continue; }
+                                    for (; x <= bend; x++) {
+                                        atomicMin(&krow[x], depth_key(z >> 16, id));
+                                        z = wadd(z, zi);
+                                    }
+                                }
+                            }
                             for (; x + 3 <= xb; x += 4) {           // four pixels per trip: constant offsets, one loop test
 #pragma unroll
                                 for (int k = 0; k < 4; k++) {
