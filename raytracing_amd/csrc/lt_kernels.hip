@@ -1594,7 +1594,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     }
     for (unsigned rd = 0; rd < rounds; rd++) {
         if (hiz) {
-            const long long *k8 = keys + (t >> 3) * KW + (t & 7) * 8;
+            const long long *k8 = keys + (t / (TW / 8)) * KW + (t % (TW / 8)) * 8;
             int m = (int)(k8[0] >> 32);
 #pragma unroll
             for (int q = 1; q < 8; q++) m = max(m, (int)(k8[q] >> 32));
