@@ -260,6 +260,10 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.queue_count = (unsigned *)(order_flag + 64);      // behind the order flag in the small device scratch
     sa.queue_cap = qcap;
     sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
+    // Screens with more tiles than the LDS histogram of the count kernel holds: set-up adds the
+    // references itself (with few tiles the adds pile up on the same words and stall set-up).
+    const bool fused = c->ntiles > BIN_MAX_TILES;
+    sa.tile_count = fused ? (unsigned *)w.tcount.p : nullptr;
     sa.status = c->status;
     launch_setup(gs, dim, screen, sa);
     if ((rc = stage_end(c, 1, gs))) return rc;
@@ -275,7 +279,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     }
     launch_binning(gs, (const PrimHdr *)w.hdr.p, np, c->tiles_x, c->ntiles, (unsigned *)w.tcount.p,
                    (unsigned *)w.toffset.p, (unsigned *)w.tcursor.p, (unsigned *)w.list.p, capacity,
-                   screen ? nullptr : sa.queue_count, c->status, scan_ev);
+                   screen ? nullptr : sa.queue_count, c->status, scan_ev, fused);
     if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
     if (timed(c, 3)) {
         lt_ctx::Span sp{3, scan_idx, 0};

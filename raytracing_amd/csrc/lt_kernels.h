@@ -37,6 +37,7 @@ constexpr int PRP_INTS = 12;
 // workgroup adds into slot blockIdx % STATUS_SLOTS: thousands of waves adding to one
 // word would queue behind each other (one chip-wide atomic per ~12 ns on one address);
 // the host sums the slots.
+constexpr int BIN_MAX_TILES = 8192;        // LDS histogram limit of the binning kernels; larger screens use direct atomics
 constexpr int STATUS_SLOTS = 256;
 constexpr int QUEUES = 64;                 // sub-queues between the fast and the general setup kernel
 constexpr int QUEUE_COUNT_STRIDE = 32;     // words between their counters (one 128-byte line each)
@@ -78,6 +79,7 @@ struct SetupArgs {
     int detect_order;
     int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
     int band_y0, band_y1;    // rows [band_y0, band_y1) are drawn by this context (whole screen: 0, H)
+    unsigned *tile_count;    // non-null: set-up counts the tile references itself (no count kernel)
     Status *status;
 };
 
@@ -125,7 +127,7 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
 // tile lists: count -> exclusive scan -> scatter (count must be zero before the call)
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    unsigned *queue_count, Status *status, hipEvent_t after_scan);
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted);
 void launch_raster(hipStream_t s, int na, const RasterArgs &a);
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a);   // textured batches only
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);

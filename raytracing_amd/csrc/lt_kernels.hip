@@ -424,6 +424,15 @@ __device__ bool tmapping_vectors(int type, const Tup<8> &p1, const Tup<8> &p2, c
 
 constexpr int KIND_FLAT = 2, KIND_SHADED = 4, KIND_TEX_LIN = 8, KIND_TEX_PRP = 9;
 
+// Counting half of the binning done where the header is made (a.tile_count != null): one
+// add per touched tile.
+__device__ __forceinline__ void count_tiles(const SetupArgs &a, int by0, int by1, int minx, int maxx)
+{
+    const int tx0 = minx / TW, tx1 = maxx / TW, ty0 = by0 / TH, ty1 = (by1 - 1) / TH;
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) atomicAdd(a.tile_count + ty * a.tiles_x + tx, 1u);
+}
+
 // 16-byte piece `piece` of the record of edge `e` of polygon `poly`: the pool is laid out
 // [edge][piece][polygon], `np` polygons.
 __device__ __forceinline__ int4 *edge_piece(int *edges, int np, int npieces, int e, int piece, int poly)
@@ -649,6 +658,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
             col = cl_light(colour, ax.x, ax.y, ax.z);
         }
         ((int4 *)a.hdr)[slot] = make_int4(by0 | (by1 << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
+        if (a.tile_count) count_tiles(a, by0, by1, minx, maxx);
     }
     if (lane >= count && base + lane < a.np) ((int4 *)a.hdr)[base + lane] = make_int4(0, 0, 0, 0);
     // queue the rest for the general kernel as {polygon, slot}: one atomic per wave,
@@ -1001,6 +1011,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
         hdr.meta = ne | (kind << 8) | ((tex < 0 ? 0 : tex) << 16);
     }
     ((int4 *)a.hdr)[slot] = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
+    if (a.tile_count && draw) count_tiles(a, miny, maxy, minx, maxx);
     if (DIM == 8 && a.detect_order) {
         const bool ord = draw && lights_vary && kind >= KIND_TEX_LIN;
         const unsigned long long om = __ballot(ord);
@@ -1046,7 +1057,6 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 constexpr int BIN_THREADS = 512;
 constexpr int BIN_PER_THREAD = 8;
 constexpr int BIN_CHUNK = BIN_THREADS * BIN_PER_THREAD;
-constexpr int BIN_MAX_TILES = 8192;        // LDS histogram limit; larger screens take the direct kernels
 
 __device__ __forceinline__ bool prim_tiles(const int4 h, int &tx0, int &tx1, int &ty0, int &ty1)
 {
@@ -1848,10 +1858,10 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
 
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    unsigned *queue_count, Status *status, hipEvent_t after_scan)
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted)
 {
     const bool lds = ntiles <= BIN_MAX_TILES;
-    if (np > 0) {
+    if (np > 0 && !counted) {
         if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, tiles_x, ntiles, count);
         else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, tiles_x, count);
     }

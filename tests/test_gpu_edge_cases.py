@@ -131,7 +131,7 @@ def test_tile_list_capacity_overflow_is_reported_and_recoverable(env):
     assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
 
 
-@pytest.mark.parametrize("w,h", [(2, 2), (3, 200), (4096, 5), (16384, 33), (70, 16384)])
+@pytest.mark.parametrize("w,h", [(2, 2), (3, 200), (4096, 5), (16384, 33), (70, 16384), (16384, 1100)])   # the last: beyond the LDS histogram of the binning
 def test_extreme_screen_shapes(env, w, h):
     P, G = env
     sc = S.gen_c2(400, w, h, 8, radius=max(2, min(w, h) // 3), seed=w * 7 + h)
