@@ -89,7 +89,7 @@ def valu_roofline(workload, tris, stage, kernel_ms):
     return None
 
 
-def cpu_baseline(sc, passes, want_frame=True):
+def cpu_baseline(sc, passes):
     """Time the CPU checker on the same scene; returns (dict, colour, depth)."""
     import oracle.port as P
     import oracle.ref as R

@@ -53,7 +53,6 @@ struct lt_ctx {
     hipStream_t own_gs = nullptr, own_rs = nullptr;    // internal streams (non-blocking)
     hipStream_t gs = nullptr, rs = nullptr;            // streams in use: own_* or `stream`
     hipEvent_t ev_fork = nullptr;
-    DevBuf view;
     DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn;      // staging for host-pointer calls
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
@@ -396,7 +395,7 @@ int lt_ctx_destroy(lt_ctx *c)
     if (c->gs) (void)hipStreamSynchronize(c->gs);
     if (c->rs) (void)hipStreamSynchronize(c->rs);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->view, &c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn};
+    DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (lt_ctx::Work &w : c->work) {
