@@ -1,0 +1,81 @@
+"""Size-independent properties at the benchmark's own sizes (1M triangles at 1080p, millions
+of clipped textured triangles at 4K), where the CPU checker would take minutes: splitting a
+submit, redrawing, and splitting the screen into bands must not change the frame."""
+import numpy as np
+import pytest
+
+from raytracing_amd import bands as B, scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from raytracing_amd import gpu as G
+    return torch, G
+
+
+def _dev(torch, sc):
+    d = dict(verts=torch.from_numpy(sc.verts).cuda(), polys=torch.from_numpy(sc.polys).cuda(),
+             pv=torch.from_numpy(sc.polyverts).cuda())
+    d["aux"] = torch.from_numpy(sc.polyaux).cuda() if sc.polyaux is not None else None
+    return d
+
+
+def _draw(ctx, sc, d, polys=None, aux=None):
+    ctx.submit_object_dev(d["verts"], d["polys"] if polys is None else polys, d["pv"], sc.render_type, sc.log_focus,
+                          d_polyaux=d["aux"] if aux is None else aux, matrix=sc.matrix, force_linear=sc.force_linear,
+                          max_edges=3)
+
+
+@pytest.mark.parametrize("which", ["c2-small-1M-1080p", "c3-lin-3M-4K"])
+def test_split_redraw_and_bands_keep_the_frame(env, which):
+    torch, G = env
+    if which.startswith("c2"):
+        sc = S.gen_c2(1_000_000, 1920, 1080, 10, radius=8)
+    else:
+        sc = S.gen_c3(3_000_000, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=100, regular_mapping=True)
+    d = _dev(torch, sc)
+    ctx = G.Context(sc.width, sc.height)
+    for h, (tex, lg) in enumerate(sc.textures):
+        ctx.texture_upload(h, tex, lg)
+
+    ctx.clear(0x010203)
+    ctx.reset_counters()
+    _draw(ctx, sc, d)
+    c0, z0 = ctx.readback()
+    n0 = ctx.counters()
+    assert n0["fragments"] > 10 * sc.width and n0["polys_drawn"] > sc.n_polys // 8
+
+    # the same polygons in four submits: draw order is call order, then array order
+    ctx.clear(0x010203)
+    ctx.reset_counters()
+    q = sc.n_polys // 4
+    for k in range(4):
+        lo, hi = k * q, (sc.n_polys if k == 3 else (k + 1) * q)
+        _draw(ctx, sc, d, polys=d["polys"][lo:hi], aux=None if d["aux"] is None else d["aux"][lo:hi])
+    c1, z1 = ctx.readback()
+    n1 = ctx.counters()
+    assert np.array_equal(c1, c0) and np.array_equal(z1, z0)
+    assert n1["fragments"] == n0["fragments"] and n1["polys_drawn"] == n0["polys_drawn"]
+
+    # drawing everything again changes nothing: equal depths keep the earlier draw
+    _draw(ctx, sc, d)
+    c2, z2 = ctx.readback()
+    assert np.array_equal(c2, c0) and np.array_equal(z2, z0)
+    assert ctx.counters()["fragments"] == 2 * n0["fragments"]
+
+    # three row bands, stitched
+    c3 = np.empty_like(c0)
+    z3 = np.empty_like(z0)
+    frags = 0
+    for y0, y1 in B.all_bands(3, sc.height):
+        ctx.set_band(y0, y1)
+        ctx.clear(0x010203)
+        ctx.reset_counters()
+        _draw(ctx, sc, d)
+        cb, zb = ctx.readback()
+        c3[y0:y1], z3[y0:y1] = cb[y0:y1], zb[y0:y1]
+        frags += ctx.counters()["fragments"]
+    assert np.array_equal(c3, c0) and np.array_equal(z3, z0) and frags == n0["fragments"]
