@@ -27,6 +27,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+import oracle.port as P  # noqa: E402
 import oracle.ref as R  # noqa: E402
 from raytracing_amd import scenes as S  # noqa: E402
 
@@ -325,7 +326,19 @@ def shade_kats():
     return out
 
 
+def bench_frame():
+    """The benchmark's own frame (1M Gouraud triangles at 1080p), drawn by the reference build."""
+    sc = S.gen_c2(1_000_000, 1920, 1080, 10, radius=8)
+    ref = R.Ref(sc.width, sc.height)
+    ref.clear(0, 0, 0, 0)
+    ref.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type, sc.log_focus)
+    c, z = ref.cbuf().copy(), ref.zbuf().copy()
+    return dict(workload="c2-small: gen_c2(1000000, 1920, 1080, 10, radius=8), clear 0", colour=S.frame_digest(c),
+                depth=S.frame_digest(z), drawn_pixels=int((z != 2 ** 31 - 1).sum()))
+
+
 def main():
+    json.dump(bench_frame(), open(os.path.join(HERE, "bench_frame.json"), "w"), indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "shade_kats.npz"), **shade_kats())
     if not os.path.isdir(REFDIR):
         raise SystemExit("needs /root/reference (run in the build container)")

@@ -79,3 +79,20 @@ def test_split_redraw_and_bands_keep_the_frame(env, which):
         c3[y0:y1], z3[y0:y1] = cb[y0:y1], zb[y0:y1]
         frags += ctx.counters()["fragments"]
     assert np.array_equal(c3, c0) and np.array_equal(z3, z0) and frags == n0["fragments"]
+
+
+def test_benchmark_frame_matches_the_reference_digest(env):
+    """the benchmark's frame against the digest the reference build produced for it
+    (tests/golden/bench_frame.json, made by tests/golden/make_golden.py)"""
+    import json
+    import os
+    torch, G = env
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bench_frame.json")))
+    sc = S.gen_c2(1_000_000, 1920, 1080, 10, radius=8)
+    d = _dev(torch, sc)
+    ctx = G.Context(sc.width, sc.height)
+    ctx.clear(0)
+    _draw(ctx, sc, d)
+    c, z = ctx.readback()
+    assert S.frame_digest(c) == gold["colour"] and S.frame_digest(z) == gold["depth"]
+    assert int((z != 2**31 - 1).sum()) == gold["drawn_pixels"]
