@@ -8,7 +8,8 @@
 // (GraphicsPoly.cpp:357), so the surviving fragment of a pixel is the one with the
 // smallest (depth, draw index) pair.  The fill kernel computes exactly that minimum with
 // 64-bit LDS atomics on packed (depth, index) keys, which makes the result independent
-// of the order in which lanes, waves and workgroups happen to run.
+// of the order in which lanes, waves and workgroups happen to run.  The shading pre-pass
+// (per-vertex light, M_shade_polygon_object) is here too.
 #include "lt_kernels.h"
 #include <limits.h>
 #include <algorithm>
@@ -696,8 +697,9 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
 //   X stage  C_polygon_x_clipping  edges of the projected polygon -> x-clipped tuples
 //   S stage  GI_scan front end     y clip of each edge, increments -> edge records
 //
-// Edge records go to the polygon's own slots (poly*emax ..) while the stream runs and
-// are made visible by the header written at the end (n_edges == 0: nothing to draw).
+// Edge records go to the planes of the polygon's output slot (`slot`: given by the fast
+// kernel for queued polygons, the polygon's own index otherwise) while the stream runs
+// and are made visible by the header written at the end (n_edges == 0: nothing to draw).
 //
 // SCREEN = true starts at the X stage with already-projected tuples (the G_*_polygon
 // entry points); polys[] then holds {first, length, colour, tex} descriptors.
