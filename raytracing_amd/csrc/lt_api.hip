@@ -16,7 +16,7 @@ namespace {
 thread_local std::string g_create_error;
 
 // small device scratch: order flag (first 256 bytes), then the setup sub-queue counters
-constexpr size_t kScratchBytes = 256 + (size_t)QUEUES * QUEUE_COUNT_STRIDE * sizeof(unsigned);
+constexpr size_t kScratchBytes = 256 + 2 * (size_t)QUEUES * QUEUE_COUNT_STRIDE * sizeof(unsigned);
 
 struct DevBuf {
     void *p = nullptr;
@@ -45,6 +45,7 @@ struct lt_ctx {
     // batch before it runs on `rs`, each batch taking the set the batch two before it used.
     struct Work {
         DevBuf hdr, edges, prp, list, tcount, toffset, tcursor, queue, scratch;   // scratch: order flag + sub-queue counters
+        DevBuf sq_desc, sq_tuples, sq_queue;                                      // screen queue of the fast set-up kernel
         hipEvent_t geom_done = nullptr, raster_done = nullptr;
         bool in_use = false;
     } work[2];
@@ -232,6 +233,9 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if ((rc = ensure_zeroed(c, w.scratch, kScratchBytes))) return rc;
     const unsigned qcap = setup_queue_cap(np);
     if (!screen && (rc = ensure(c, w.queue, (size_t)qcap * QUEUES * sizeof(uint2)))) return rc;
+    if (!screen && (rc = ensure(c, w.sq_queue, (size_t)qcap * QUEUES * sizeof(uint2)))) return rc;
+    if (!screen && (rc = ensure(c, w.sq_desc, (size_t)qcap * QUEUES * sizeof(int4)))) return rc;
+    if (!screen && (rc = ensure(c, w.sq_tuples, (size_t)qcap * QUEUES * 4 * dim * sizeof(int)))) return rc;
     int *order_flag = (int *)w.scratch.p;
 
     // the transform is applied inside the setup kernel: its stage is empty
@@ -258,6 +262,10 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.queue = screen ? nullptr : (uint2 *)w.queue.p;
     sa.queue_count = (unsigned *)(order_flag + 64);      // behind the order flag in the small device scratch
     sa.queue_cap = qcap;
+    sa.queue_index_limit = (unsigned)np;
+    sa.count_drawn = 1;
+    sa.sq_desc = (int *)w.sq_desc.p; sa.sq_tuples = (int *)w.sq_tuples.p; sa.sq_queue = (uint2 *)w.sq_queue.p;
+    sa.sq_count = sa.queue_count + QUEUES * QUEUE_COUNT_STRIDE;
     sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
     // Screens with more tiles than the LDS histogram of the count kernel holds: set-up adds the
     // references itself (with few tiles the adds pile up on the same words and stall set-up).
@@ -399,7 +407,8 @@ int lt_ctx_destroy(lt_ctx *c)
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (lt_ctx::Work &w : c->work) {
-        DevBuf *wb[] = {&w.hdr, &w.edges, &w.prp, &w.list, &w.tcount, &w.toffset, &w.tcursor, &w.queue, &w.scratch};
+        DevBuf *wb[] = {&w.hdr, &w.edges, &w.prp, &w.list, &w.tcount, &w.toffset, &w.tcursor, &w.queue, &w.scratch,
+                        &w.sq_desc, &w.sq_tuples, &w.sq_queue};
         for (DevBuf *b : wb)
             if (b->p) (void)hipFree(b->p);
         if (w.geom_done) (void)hipEventDestroy(w.geom_done);

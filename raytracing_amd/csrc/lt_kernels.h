@@ -74,6 +74,13 @@ struct SetupArgs {
     uint2 *queue;            // {polygon, output slot} left to the general kernel by the fast one (null: it takes all, slot = polygon)
     unsigned *queue_count;   // QUEUES counters, QUEUE_COUNT_STRIDE words apart
     unsigned queue_cap;      // entries per sub-queue
+    unsigned queue_index_limit;  // queue entries name polygons below this (np, or the screen queue's size)
+    int count_drawn;         // 0: polys_drawn has been counted by the kernel that queued the polygons
+    // screen queue (object batches): projected triangles that meet a screen border
+    int *sq_desc;            // int4 per entry {first tuple, 3 | kind<<8, colour, tex}
+    int *sq_tuples;          // 4 tuples of DIM ints per entry
+    uint2 *sq_queue;         // {entry, output slot}
+    unsigned *sq_count;      // QUEUES counters, QUEUE_COUNT_STRIDE words apart
     int *order_flag;         // device word set to order_gen when a textured polygon's vertex lights differ
     int order_gen;           // this batch's number (never 0): a stale flag of an earlier batch does not count
     int detect_order;

@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
     int4 *stg = stage_f[threadIdx.x >> 6];
     const bool inrange = poly < a.np;
     const bool wave_full = __ballot(inrange) == ~0ull;
-    bool slow = false, drawn = false, vary = false, offscreen = false, visible = false;
+    bool slow = false, drawn = false, vary = false, offscreen = false, visible = false, straddles = false;
     Tup<DIM> t[4];
     int colour = 0, tex = 0, kind = a.render_type, by0 = 0, by1 = 0, minx = 0, maxx = 0;
     if (inrange) {
@@ -620,7 +620,9 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
             // between their edge's ends -- so nothing is drawn; the polygon still counts
             // as drawn if it faces the viewer, as in M_render_polygon.
             offscreen = left || right || above || below;
-            if (!inside && !offscreen) { slow = true; go = false; }
+            // neither: the polygon meets a screen border and goes, projected, to the screen-level
+            // set-up (x and y clipping) if it faces the viewer
+            straddles = !inside && !offscreen;
         }
         if (go) {
             // T_normal_z_negative, TransLn.cpp:218-223
@@ -636,8 +638,9 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
             // rows outside the band of this context are another context's to draw
             by0 = max(miny, a.band_y0);
             by1 = min(maxy, a.band_y1);
-            visible = by0 < by1 && !offscreen;
+            visible = by0 < by1 && !offscreen && !straddles;
         }
+        straddles = straddles && go;
     }
     // Output slots.  About half of a soup's triangles face away, and writing records with
     // holes between them costs more HBM time than writing twice as many without (partial
@@ -646,7 +649,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
     // rest of the 64 headers is zeroed.  Slot order is polygon order, and everything after
     // set-up (binning, fill, draw-order ties) knows a polygon by its slot.
     const unsigned long long below = (1ull << lane) - 1ull;
-    const unsigned long long keep = __ballot(visible || slow);
+    const unsigned long long keep = __ballot(visible || slow || straddles);
     const int base = poly & ~63, count = __popcll(keep);
     const int slot = base + __popcll(keep & below);
     if (visible) {
@@ -675,11 +678,37 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
         qbase = __shfl(qbase, leader);
         if (slow) a.queue[(size_t)q * a.queue_cap + qbase + __popcll(sm & below)] = make_uint2((unsigned)poly, (unsigned)slot);
     }
+    // Triangles that meet a screen border: their four projected tuples go to the screen
+    // queue, as {first, edges | kind<<8, colour, tex} + tuples, for the set-up kernel in
+    // screen mode (what M_render_polygon hands to G_*_polygon, EngBase.cpp:451-545).
+    const unsigned long long qm = __ballot(straddles);
+    if (qm) {
+        const int leader = __ffsll((long long)qm) - 1;
+        const int q = blockIdx.x % QUEUES;
+        unsigned qbase = 0;
+        if (lane == leader) qbase = atomicAdd(a.sq_count + q * QUEUE_COUNT_STRIDE, (unsigned)__popcll(qm));
+        qbase = __shfl(qbase, leader);
+        if (straddles) {
+            const unsigned idx = (unsigned)q * a.queue_cap + qbase + __popcll(qm & below);
+            int col = colour;
+            if (kind == KIND_FLAT) {
+                const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
+                col = cl_light(colour, ax.x, ax.y, ax.z);
+            }
+            ((int4 *)a.sq_desc)[idx] = make_int4((int)(idx * 4u), 3 | (kind << 8), col, tex < 0 ? 0 : tex);
+            int *dst = a.sq_tuples + (size_t)idx * 4 * DIM;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < DIM; j++) dst[i * DIM + j] = t[i].v[j];
+            a.sq_queue[idx] = make_uint2(idx, (unsigned)slot);
+        }
+    }
     Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
     const unsigned long long dm = __ballot(drawn);
     if (dm && (threadIdx.x & 63) == (__ffsll((long long)dm) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(dm));
     if (DIM == 8 && a.detect_order) {
-        const unsigned long long om = __ballot(drawn && vary && !offscreen);
+        const unsigned long long om = __ballot(visible && vary);
         if (om && (threadIdx.x & 63) == (__ffsll((long long)om) - 1)) *a.order_flag = a.order_gen;
     }
 }
@@ -713,13 +742,14 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
 
     const int4 pd = ((const int4 *)a.polys)[poly];
     int colour, tex, e, first;
-    if (SCREEN) { first = pd.x; e = pd.y; colour = pd.z; tex = pd.w; }
+    if (SCREEN) { first = pd.x; e = pd.y & 0xff; colour = pd.z; tex = pd.w; }
     else        { colour = pd.x; tex = pd.y; e = pd.z; first = pd.w; }
 
     bool bad = false;        // polygon cannot be processed (limits); counted, not drawn
     bool unsupported = false;
     int kind = a.render_type;
     if (!SCREEN && kind == KIND_TEX_LIN && tex < 0) kind = KIND_SHADED;   // EngBase.cpp:470,518-522
+    if (SCREEN && (pd.y >> 8) != 0) kind = pd.y >> 8;      // screen queue: the fast kernel has chosen the fill
 
     bool go = true;
     if (e < 2 || e + 1 > 16 || e > a.max_edges || first < 0 || (long long)first + e + 1 > (long long)a.npv) {
@@ -1023,7 +1053,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
     // counters: one atomic per wave, spread over the status slots
     Status *st = a.status + ((blockIdx.x + blockIdx.y) % STATUS_SLOTS);
     unsigned long long m;
-    m = __ballot(reached_fill);
+    m = __ballot(reached_fill && a.count_drawn);
     if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(m));
     m = __ballot(bad);
     if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->overflow_polys, (unsigned long long)__popcll(m));
@@ -1041,7 +1071,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
         const unsigned cnt = min(a.queue_count[blockIdx.y * QUEUE_COUNT_STRIDE], a.queue_cap);
         for (unsigned qi = blockIdx.x * blockDim.x + threadIdx.x; qi < cnt; qi += gridDim.x * blockDim.x) {
             const uint2 e = a.queue[(size_t)blockIdx.y * a.queue_cap + qi];
-            if (e.x < (unsigned)a.np && e.y < (unsigned)a.np) setup_one<DIM, SCREEN>(a, (int)e.x, (int)e.y);
+            if (e.x < a.queue_index_limit && e.y < (unsigned)a.np) setup_one<DIM, SCREEN>(a, (int)e.x, (int)e.y);
         }
     } else {
         const int poly = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1215,7 +1245,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(unsigned *__restrict__ count
         }
         if (i < n) { offset[i] = wsum[st * 16 + w] + s - v; cursor[i] = 0u; count[i] = 0u; }
     }
-    if (queue_count && t < QUEUES) queue_count[t * QUEUE_COUNT_STRIDE] = 0u;
+    if (queue_count && t < 2 * QUEUES) queue_count[t * QUEUE_COUNT_STRIDE] = 0u;      // general queue, then screen queue
     if (t == 0) {
         offset[n] = total;
         atomicAdd(&status->tile_refs, (unsigned long long)total);
@@ -1839,23 +1869,40 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
 {
     if (a.np <= 0) return;
     dim3 g((a.np + SETUP_THREADS - 1) / SETUP_THREADS), b(SETUP_THREADS);
-    if (!screen && a.queue) g = dim3(std::min((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, 8u), QUEUES);
-    if (!screen && a.queue) {
-        // fast kernel for unclipped triangles; it queues the rest for the general kernel
-        dim3 gf((a.np + 255) / 256), bf(256);
-        if (dim == 3) hipLaunchKernelGGL((setup_fast_kernel<3>), gf, bf, 0, s, a);
-        else if (dim == 6) hipLaunchKernelGGL((setup_fast_kernel<6>), gf, bf, 0, s, a);
-        else hipLaunchKernelGGL((setup_fast_kernel<8>), gf, bf, 0, s, a);
+    if (screen || !a.queue) {
+        // every polygon through the general kernel
+        if (screen) {
+            if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, true>), g, b, 0, s, a);
+            else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, true>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((setup_kernel<8, true>), g, b, 0, s, a);
+        } else {
+            if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, false>), g, b, 0, s, a);
+            else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, false>), g, b, 0, s, a);
+            else hipLaunchKernelGGL((setup_kernel<8, false>), g, b, 0, s, a);
+        }
+        return;
     }
-    if (screen) {
-        if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, true>), g, b, 0, s, a);
-        else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((setup_kernel<8, true>), g, b, 0, s, a);
-    } else {
-        if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, false>), g, b, 0, s, a);
-        else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, false>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((setup_kernel<8, false>), g, b, 0, s, a);
-    }
+    // fast kernel for unclipped triangles; it queues the rest: triangles that only meet a
+    // screen border for the screen-mode kernel (projected tuples), everything else for the
+    // general kernel
+    dim3 gf((a.np + SETUP_FAST_THREADS - 1) / SETUP_FAST_THREADS), bf(SETUP_FAST_THREADS);
+    if (dim == 3) hipLaunchKernelGGL((setup_fast_kernel<3>), gf, bf, 0, s, a);
+    else if (dim == 6) hipLaunchKernelGGL((setup_fast_kernel<6>), gf, bf, 0, s, a);
+    else hipLaunchKernelGGL((setup_fast_kernel<8>), gf, bf, 0, s, a);
+    g = dim3(std::min((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, 8u), QUEUES);
+    if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, false>), g, b, 0, s, a);
+    else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((setup_kernel<8, false>), g, b, 0, s, a);
+    SetupArgs q = a;
+    q.polys = a.sq_desc; q.polyverts = a.sq_tuples; q.polyaux = nullptr;
+    q.npv = (int)std::min<unsigned long long>((unsigned long long)QUEUES * a.queue_cap * 4ull, 0x7fffffffull);
+    q.queue = a.sq_queue; q.queue_count = a.sq_count;
+    q.queue_index_limit = QUEUES * a.queue_cap;
+    q.count_drawn = 0;              // the fast kernel has counted them
+    q.use_matrix = 0;
+    if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, true>), g, b, 0, s, q);
+    else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, true>), g, b, 0, s, q);
+    else hipLaunchKernelGGL((setup_kernel<8, true>), g, b, 0, s, q);
 }
 
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
