@@ -1079,6 +1079,36 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
     }
 }
 
+// Both queues of the fast kernel in one launch: rows 0..QUEUES-1 of the grid take the
+// projected triangles (screen mode), rows QUEUES..2*QUEUES-1 the polygons that need the
+// whole path.  One launch instead of two: the second kernel is nearly always almost empty,
+// and an empty launch still costs its dispatch, several times over when the chip is busy
+// with the fill of the previous batch.
+template <int DIM>
+__global__ void __launch_bounds__(SETUP_THREADS) setup_queues_kernel(SetupArgs a)
+{
+    if (blockIdx.y < QUEUES) {
+        SetupArgs q = a;
+        q.polys = a.sq_desc; q.polyverts = a.sq_tuples; q.polyaux = nullptr;
+        q.npv = (int)min((unsigned long long)QUEUES * a.queue_cap * 4ull, 0x7fffffffull);
+        q.queue_index_limit = QUEUES * a.queue_cap;
+        q.count_drawn = 0;              // the fast kernel has counted them
+        q.use_matrix = 0;
+        const unsigned cnt = min(a.sq_count[blockIdx.y * QUEUE_COUNT_STRIDE], a.queue_cap);
+        for (unsigned qi = blockIdx.x * blockDim.x + threadIdx.x; qi < cnt; qi += gridDim.x * blockDim.x) {
+            const uint2 e = a.sq_queue[(size_t)blockIdx.y * a.queue_cap + qi];
+            if (e.x < q.queue_index_limit && e.y < (unsigned)a.np) setup_one<DIM, true>(q, (int)e.x, (int)e.y);
+        }
+    } else {
+        const unsigned y = blockIdx.y - QUEUES;
+        const unsigned cnt = min(a.queue_count[y * QUEUE_COUNT_STRIDE], a.queue_cap);
+        for (unsigned qi = blockIdx.x * blockDim.x + threadIdx.x; qi < cnt; qi += gridDim.x * blockDim.x) {
+            const uint2 e = a.queue[(size_t)y * a.queue_cap + qi];
+            if (e.x < a.queue_index_limit && e.y < (unsigned)a.np) setup_one<DIM, false>(a, (int)e.x, (int)e.y);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ binning
 
 // Tile lists are built by a counting sort over (polygon, tile) references: count per
@@ -1889,20 +1919,10 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
     if (dim == 3) hipLaunchKernelGGL((setup_fast_kernel<3>), gf, bf, 0, s, a);
     else if (dim == 6) hipLaunchKernelGGL((setup_fast_kernel<6>), gf, bf, 0, s, a);
     else hipLaunchKernelGGL((setup_fast_kernel<8>), gf, bf, 0, s, a);
-    g = dim3(std::min((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, 8u), QUEUES);
-    if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, false>), g, b, 0, s, a);
-    else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((setup_kernel<8, false>), g, b, 0, s, a);
-    SetupArgs q = a;
-    q.polys = a.sq_desc; q.polyverts = a.sq_tuples; q.polyaux = nullptr;
-    q.npv = (int)std::min<unsigned long long>((unsigned long long)QUEUES * a.queue_cap * 4ull, 0x7fffffffull);
-    q.queue = a.sq_queue; q.queue_count = a.sq_count;
-    q.queue_index_limit = QUEUES * a.queue_cap;
-    q.count_drawn = 0;              // the fast kernel has counted them
-    q.use_matrix = 0;
-    if (dim == 3) hipLaunchKernelGGL((setup_kernel<3, true>), g, b, 0, s, q);
-    else if (dim == 6) hipLaunchKernelGGL((setup_kernel<6, true>), g, b, 0, s, q);
-    else hipLaunchKernelGGL((setup_kernel<8, true>), g, b, 0, s, q);
+    g = dim3(std::min((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, 8u), 2 * QUEUES);
+    if (dim == 3) hipLaunchKernelGGL((setup_queues_kernel<3>), g, b, 0, s, a);
+    else if (dim == 6) hipLaunchKernelGGL((setup_queues_kernel<6>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((setup_queues_kernel<8>), g, b, 0, s, a);
 }
 
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
