@@ -215,15 +215,19 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     lt_ctx::Work &w = c->work[c->batch_no & 1u];
     hipStream_t gs = c->gs, rs = c->rs;
     if (c->pipelined) {
-        // the inputs may have been produced on the caller's stream
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(gs, c->ev_fork, 0));
+        // the inputs may have been produced on the caller's stream; an idle stream has
+        // nothing to wait for, and every wait costs the set-up stream a few microseconds
+        if (hipStreamQuery(c->stream) != hipSuccess) {
+            (void)hipGetLastError();        // "not ready" is an answer, not an error
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(gs, c->ev_fork, 0));
+        }
         // this workspace set is free once the fill of the batch two before this one is done
         if (w.in_use) HIPCHK(c, hipStreamWaitEvent(gs, w.raster_done, 0));
     }
     if ((rc = ensure(c, w.hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
     // the fill fetches edges 0..2 of every listed polygon without waiting for its header: at least three planes
-    if ((rc = ensure(c, w.edges, (size_t)np * (emax < 3 ? 3 : emax) * edge_ints(na) * sizeof(int)))) return rc;
+    if ((rc = ensure(c, w.edges, (size_t)np * (16 + (emax < 3 ? 3 : emax) * edge_ints(na) * sizeof(int))))) return rc;
     if ((rc = ensure(c, w.list, (size_t)capacity * sizeof(unsigned)))) return rc;
     const bool want_prp = !screen && dim == 8;
     if (want_prp && (rc = ensure(c, w.prp, (size_t)np * PRP_INTS * sizeof(int)))) return rc;

@@ -434,23 +434,31 @@ __device__ __forceinline__ void count_tiles(const SetupArgs &a, int by0, int by1
         for (int tx = tx0; tx <= tx1; tx++) atomicAdd(a.tile_count + ty * a.tiles_x + tx, 1u);
 }
 
-// 16-byte piece `piece` of the record of edge `e` of polygon `poly`: the pool is laid out
-// [edge][piece][polygon], `np` polygons.
+// 16-byte piece `piece` of the record of edge `e` of polygon `poly`.  Edges 0..2 of a
+// polygon lie together in one record of record_units() pieces: unit 0 is a copy of the
+// header, units 1..3 the depth pieces (piece 0) of the three edges, so that the depth pass
+// of a triangle reads one 64-byte run; the other pieces follow edge by edge.  Edges 3 and up
+// are planes [edge][piece][polygon] behind the records.
+__host__ __device__ constexpr int record_units(int npieces) { return 4 + 3 * (npieces - 1); }
+__device__ __forceinline__ size_t edge_unit(int np, int npieces, int e, int piece, int poly)
+{
+    if (e < 3) return (size_t)poly * record_units(npieces) + (piece == 0 ? 1 + e : 4 + e * (npieces - 1) + (piece - 1));
+    return (size_t)np * record_units(npieces) + ((size_t)((e - 3) * npieces + piece) * np + poly);
+}
 __device__ __forceinline__ int4 *edge_piece(int *edges, int np, int npieces, int e, int piece, int poly)
 {
-    return (int4 *)edges + ((size_t)(e * npieces + piece) * np + poly);
+    return (int4 *)edges + edge_unit(np, npieces, e, piece, poly);
 }
 __device__ __forceinline__ const int4 *edge_piece(const int *edges, int np, int npieces, int e, int piece, int poly)
 {
-    return (const int4 *)edges + ((size_t)(e * npieces + piece) * np + poly);
+    return (const int4 *)edges + edge_unit(np, npieces, e, piece, poly);
 }
 
 // Edge record of one scanned edge v1 -> v2 (after the y clip): GI_scan's set-up,
 // GraphicsPoly.cpp:147-176.  record = {x1|y1<<16, x2|y2<<16, Zstart, Zinc, other starts..,
 // other incs..} in 16-byte pieces; edge `slot` of every polygon lies in plane `slot`.
 template <int DIM>
-__device__ __forceinline__ void store_edge_record(const SetupArgs &a, int poly, int slot, const Tup<DIM> &v1,
-                                                  const Tup<DIM> &v2)
+__device__ __forceinline__ void make_edge_record(const Tup<DIM> &v1, const Tup<DIM> &v2, int (&rec)[edge_ints(DIM - 2)])
 {
     constexpr int NA = DIM - 2;
     constexpr int ESZ = edge_ints(NA);
@@ -459,7 +467,6 @@ __device__ __forceinline__ void store_edge_record(const SetupArgs &a, int poly, 
     dx = dx < 0 ? -dx : dx;
     dy = dy < 0 ? -dy : dy;
     const int L = dx > dy ? dx : dy;
-    int rec[ESZ];
 #pragma unroll
     for (int q = 0; q < ESZ; q++) rec[q] = 0;
     rec[0] = x1 | (y1 << 16);
@@ -472,11 +479,28 @@ __device__ __forceinline__ void store_edge_record(const SetupArgs &a, int poly, 
         rec[3 + q] = v1.v[2 + q];
         rec[3 + (NA - 1) + q] = L > 0 ? tdivr(wsub(v2.v[2 + q], v1.v[2 + q]), rL) : 0;
     }
-    // piece q of edge `slot` of all polygons is one array: consecutive lanes (polygons)
-    // store adjacent 16-byte pieces
+}
+
+template <int DIM>
+__device__ __forceinline__ void store_edge_record(const SetupArgs &a, int poly, int slot, const Tup<DIM> &v1,
+                                                  const Tup<DIM> &v2)
+{
+    constexpr int ESZ = edge_ints(DIM - 2);
+    int rec[ESZ];
+    make_edge_record<DIM>(v1, v2, rec);
 #pragma unroll
     for (int q = 0; q < ESZ / 4; q++)
         *edge_piece(a.edges, a.np, ESZ / 4, slot, q, poly) = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+}
+
+// The header copy at the front of a polygon's record (what the fill reads).
+__device__ __forceinline__ int4 *record_header(int *edges, int npieces, int poly)
+{
+    return (int4 *)edges + (size_t)poly * record_units(npieces);
+}
+__device__ __forceinline__ const int4 *record_header(const int *edges, int npieces, int poly)
+{
+    return (const int4 *)edges + (size_t)poly * record_units(npieces);
 }
 
 // Triangles that need no clipping at all take this kernel: volume test passed with every
@@ -491,7 +515,11 @@ template <int DIM>
 __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArgs a)
 {
     constexpr int NA = DIM - 2;
-    __shared__ int4 stage_f[SETUP_FAST_THREADS / 64][6 * 64];     // per wave: 64 x 4 vertex records of 24 bytes
+    constexpr int ESZ = edge_ints(NA);
+    constexpr int RU = record_units(ESZ / 4);
+    // per wave: 64 x 4 vertex records of 24 bytes on the way in, 32 polygon records on the way out
+    constexpr int STAGE_UNITS = 6 * 64 > 32 * RU ? 6 * 64 : 32 * RU;
+    __shared__ int4 stage_f[SETUP_FAST_THREADS / 64][STAGE_UNITS];
     const int poly = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int4 *stg = stage_f[threadIdx.x >> 6];
@@ -652,17 +680,50 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
     const unsigned long long keep = __ballot(visible || slow || straddles);
     const int base = poly & ~63, count = __popcll(keep);
     const int slot = base + __popcll(keep & below);
+    // A lane's record is 16*RU contiguous bytes, RU pieces apart from its neighbour's: stored
+    // lane by lane every store instruction would touch 64 different lines.  The wave builds
+    // its records in LDS, 32 slots at a time, and writes the run of slots it owns with
+    // consecutive 16-byte stores.  Slots left to the queue kernels get zeros here and their
+    // records later.
+    int4 R[RU];
+#pragma unroll
+    for (int q = 0; q < RU; q++) R[q] = make_int4(0, 0, 0, 0);
     if (visible) {
-        store_edge_record<DIM>(a, slot, 0, t[1], t[2]);
-        store_edge_record<DIM>(a, slot, 1, t[2], t[3]);
-        store_edge_record<DIM>(a, slot, 2, t[3], t[1]);
         int col = colour;
         if (kind == KIND_FLAT) {
             const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
             col = cl_light(colour, ax.x, ax.y, ax.z);
         }
-        ((int4 *)a.hdr)[slot] = make_int4(by0 | (by1 << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
+        R[0] = make_int4(by0 | (by1 << 16), minx | (maxx << 16), col, 3 | (kind << 8) | ((tex < 0 ? 0 : tex) << 16));
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            int rec[ESZ];
+            make_edge_record<DIM>(t[1 + e], t[e == 2 ? 1 : 2 + e], rec);
+            R[1 + e] = make_int4(rec[0], rec[1], rec[2], rec[3]);
+#pragma unroll
+            for (int q = 1; q < ESZ / 4; q++)
+                R[4 + e * (ESZ / 4 - 1) + (q - 1)] = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
+        }
+        ((int4 *)a.hdr)[slot] = R[0];
         if (a.tile_count) count_tiles(a, by0, by1, minx, maxx);
+    }
+    {
+        const bool kept = (keep >> lane) & 1ull;
+        const int rank = slot - base;
+        int4 *out = (int4 *)a.edges + (size_t)base * RU;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (count > 32 * half) {
+                if (kept && (rank >> 5) == half) {
+#pragma unroll
+                    for (int q = 0; q < RU; q++) stg[(rank & 31) * RU + q] = R[q];
+                }
+                LDS_WAVE_SYNC();
+                const int n = (min(count, 32 * half + 32) - 32 * half) * RU;
+                for (int u = lane; u < n; u += 64) out[32 * half * RU + u] = stg[u];
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
     if (lane >= count && base + lane < a.np) ((int4 *)a.hdr)[base + lane] = make_int4(0, 0, 0, 0);
     // queue the rest for the general kernel as {polygon, slot}: one atomic per wave,
@@ -1043,6 +1104,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
         hdr.meta = ne | (kind << 8) | ((tex < 0 ? 0 : tex) << 16);
     }
     ((int4 *)a.hdr)[slot] = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
+    *record_header(a.edges, ESZ / 4, slot) = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
     if (a.tile_count && draw) count_tiles(a, miny, maxy, minx, maxx);
     if (DIM == 8 && a.detect_order) {
         const bool ord = draw && lights_vary && kind >= KIND_TEX_LIN;
@@ -1659,7 +1721,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     if ((unsigned)poly_n >= npu) poly_n = -1;
     int4 h_c = zero4, e0_c = zero4, e1_c = zero4, e2_c = zero4;
     if (poly_c >= 0) {
-        h_c = ((const int4 *)a.hdr)[poly_c];
+        h_c = *record_header(a.edges, ESZ / 4, poly_c);
         e0_c = *edge_piece(a.edges, a.np, ESZ / 4, 0, 0, poly_c);
         e1_c = *edge_piece(a.edges, a.np, ESZ / 4, 1, 0, poly_c);
         e2_c = *edge_piece(a.edges, a.np, ESZ / 4, 2, 0, poly_c);
@@ -1674,7 +1736,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
         }
         int4 h_n = zero4, e0_n = zero4, e1_n = zero4, e2_n = zero4;
         if (poly_n >= 0) {
-            h_n = ((const int4 *)a.hdr)[poly_n];
+            h_n = *record_header(a.edges, ESZ / 4, poly_n);
             e0_n = *edge_piece(a.edges, a.np, ESZ / 4, 0, 0, poly_n);
             e1_n = *edge_piece(a.edges, a.np, ESZ / 4, 1, 0, poly_n);
             e2_n = *edge_piece(a.edges, a.np, ESZ / 4, 2, 0, poly_n);
@@ -1809,7 +1871,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
             const unsigned id = (unsigned)kk[g];
             if (id != 0u) {
                 const int poly = (int)(id - 1u);
-                hh[g] = ((const int4 *)a.hdr)[poly];
+                hh[g] = *record_header(a.edges, ESZ / 4, poly);
                 if (NA > 1) {
 #pragma unroll
                     for (int e = 0; e < 3; e++) xy[g][e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
