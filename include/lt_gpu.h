@@ -137,9 +137,10 @@ int lt_reset_counters(lt_ctx *ctx);
  * reference, which has no timers).  on = 1: every stage of every submit is bracketed by
  * events; any other value is a mask of the stages to time (bit k = stage k, e.g. 16 = the
  * fill only): an event costs a few microseconds of stream time, so time only what is
- * needed inside a measured region.  lt_get_stage_ms implies lt_flush and returns, summed
- * since the last call, the milliseconds of {transform, setup, scan, bin, fill} and the
- * number of submits. */
+ * needed inside a measured region.  With a mask, bits 8 and up hold a sampling period n
+ * (on = mask | n << 8, n > 1): only every n-th submit is timed.  lt_get_stage_ms implies
+ * lt_flush and returns, summed since the last call, the milliseconds of {transform, setup,
+ * scan, bin, fill} and the number of submits that were timed. */
 #define LT_STAGES 5
 int lt_set_profiling(lt_ctx *ctx, int on);
 int lt_get_stage_ms(lt_ctx *ctx, double ms[LT_STAGES], int *submits);

@@ -62,6 +62,7 @@ struct lt_ctx {
     int *tex_log_d = nullptr;
     // stage timing
     int profiling = 0;                 // bit k: stage k is timed
+    unsigned profile_every = 1;        // ... in every profile_every-th batch
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     struct Span { int stage; size_t begin, end; };      // indices into ev_pool
@@ -122,7 +123,10 @@ int new_event(lt_ctx *c, hipStream_t s, size_t *idx)
     return LT_OK;
 }
 
-bool timed(const lt_ctx *c, int stage) { return (c->profiling >> stage) & 1; }
+bool timed(const lt_ctx *c, int stage)
+{
+    return ((c->profiling >> stage) & 1) && c->batch_no % c->profile_every == 0;
+}
 
 int stage_begin(lt_ctx *c, int stage, hipStream_t s)
 {
@@ -326,7 +330,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         w.in_use = true;
     }
     c->batch_no++;
-    if (c->profiling) c->timed_batches++;
+    if (c->profiling && (c->batch_no - 1) % c->profile_every == 0) c->timed_batches++;
 
     c->clear_pending = false;
     c->frame_defined = true;
@@ -621,6 +625,7 @@ int lt_set_profiling(lt_ctx *c, int on)
     if ((rc = sync_all(c))) return rc;
     if ((rc = collect(c))) return rc;
     c->profiling = on == 1 ? (1 << LT_STAGES) - 1 : (on & ((1 << LT_STAGES) - 1));
+    c->profile_every = on > 1 && (on >> 8) > 1 ? (unsigned)(on >> 8) : 1u;
     return LT_OK;
 }
 

@@ -111,8 +111,9 @@ class Context:
 
     STAGES = ("transform", "setup", "scan", "bin", "fill")
 
-    def set_profiling(self, on):
-        """True/False, or a stage name / list of stage names to time only those"""
+    def set_profiling(self, on, every=1):
+        """True/False, or a stage name / list of stage names to time only those; every = n
+        (with stage names) times only every n-th submit"""
         if isinstance(on, str):
             on = [on]
         if isinstance(on, (list, tuple)):
@@ -120,6 +121,8 @@ class Context:
             for name in on:
                 mask |= 1 << self.STAGES.index(name)
             on = mask if mask != 1 else 1
+            if every > 1 and on != 1:
+                on |= int(every) << 8
         self._chk(self.L.lt_set_profiling(self.h_ctx, int(on)))
 
     def stage_ms(self):
