@@ -193,6 +193,22 @@ int lt_shade_object(lt_ctx *ctx, const int32_t s9[9], int32_t x, int32_t y, int3
                     const int32_t *polynormals, int npv, int32_t *polyaux,
                     const lt_light *lights, int nlights);
 
+/* The plane normals of M_init_polygon_object (EngPoly.cpp:392-398): for every polygon,
+ * T_normal_plane (TransLn.cpp:150-171) of the vertices of its first three records:
+ * d_plane_normals[p] = {nx, ny, nz, 0}, unit length scaled by 1<<7.  These are the m_normals
+ * of an object of M_PLANNAR polygons (one normal per polygon, index = polygon); the list
+ * handling of M_init_polygon_object (shared indices, the averaged vertex normals of M_CURVED
+ * polygons, EngPoly.cpp:399-458) is sequential host work on top of them (host mirror:
+ * M_init_polygon_object).  Runs on the caller's stream.  A zero-length normal stops the
+ * reference (TransLn.cpp:166); here it is stored as {0,0,0,0} and lt_flush reports
+ * LT_ERR_UNSUPPORTED. */
+int lt_plane_normals_dev(lt_ctx *ctx, const int32_t *d_verts, int nv, const int32_t *d_polys, int np,
+                         const int32_t *d_polyverts, int npv, int32_t *d_plane_normals);
+/* The same on host arrays; plane_normals int32[np][4] is filled before the call returns and
+ * a zero-length normal is reported by this call. */
+int lt_plane_normals(lt_ctx *ctx, const int32_t *verts, int nv, const int32_t *polys, int np,
+                     const int32_t *polyverts, int npv, int32_t *plane_normals);
+
 /* M_render_polygon_object (EngPoly.cpp:499-525) for one object of np polygons, after
  * the host has built the matrix (T_set_self_rotation + T_cancatinate_self_world):
  * transform, then per polygon what M_render_polygon does (EngBase.cpp:379-552) --

@@ -904,3 +904,104 @@ int lto_shade_polys(const i32 *s9,i32 x,i32 y,i32 z,const i32 *verts,int nv,cons
     if(bad_polys) *bad_polys=bad;
     return skipped;
 }
+
+/* ------------------------------------------------------------------ normals (object set-up) */
+
+/* T_normal_plane, TransLn.cpp:150-171: unit normal (T_LOG_NORMAL_SIZE fraction bits) of the
+ * plane through three points; products wrap in 32 bits as the reference's int arithmetic
+ * does.  Returns 0 where the reference stops with "Found a zero length vector". */
+int lto_normal_plane(const i32 *from1,const i32 *from2,const i32 *from3,i32 *to)
+{
+    i32 v[3],w[3],n[3];
+    i64 lng;
+    v[0]=wsub(from2[0],from1[0]); v[1]=wsub(from2[1],from1[1]); v[2]=wsub(from2[2],from1[2]);
+    w[0]=wsub(from3[0],from1[0]); w[1]=wsub(from3[1],from1[1]); w[2]=wsub(from3[2],from1[2]);
+    n[0]=wsub(wmul(v[1],w[2]),wmul(v[2],w[1]));
+    n[1]=wsub(wmul(v[2],w[0]),wmul(v[0],w[2]));
+    n[2]=wsub(wmul(v[0],w[1]),wmul(v[1],w[0]));
+    lng=t_norm(n);
+    if(lng==0) return 0;
+    to[0]=(i32)((((i64)n[0])*(1<<LTO_LOG_NORMAL))/lng);
+    to[1]=(i32)((((i64)n[1])*(1<<LTO_LOG_NORMAL))/lng);
+    to[2]=(i32)((((i64)n[2])*(1<<LTO_LOG_NORMAL))/lng);
+    return 1;
+}
+
+/* MI_add_tuple, EngPoly.cpp:46-63: index of an X Y Z tuple in the list, appended if new;
+ * -1 where the reference stops with "Not enough internal storage for vertices". */
+static int add_tuple(i32 *list,int *count,int limit,const i32 *t)
+{
+    int i;
+    for(i=0;i<*count;i++)
+        if(list[i*4]==t[0]&&list[i*4+1]==t[1]&&list[i*4+2]==t[2]) return i;
+    if(i>=limit) return -1;
+    list[i*4]=t[0]; list[i*4+1]=t[1]; list[i*4+2]=t[2];
+    return (*count)++;
+}
+
+/* The normals half of M_init_polygon_object, EngPoly.cpp:390-458 (no BSP ordering: the
+ * pinned build has a depth buffer).  verts[nv][4]; polys[np][4] = {colour, tex, n_edges,
+ * first}; types[np] = m_type (M_PLANNAR 1, M_CURVED 2); polyverts[*][6] vertex records.
+ * normals[limit][4] receives the list (X Y Z; the fourth word is left as it is),
+ * polynormals[*] the index per record, laid out like polyverts (entries of polygons that
+ * are neither planar nor curved are left as they are: the reference leaves m_normals NULL).
+ * Returns the number of normals, -1 for a zero-length plane normal, -2 for a full list. */
+int lto_init_normals(const i32 *verts,int nv,const i32 *polys,const i32 *types,int np,
+                     const i32 *polyverts,i32 *normals,int limit,i32 *polynormals)
+{
+    i32 *plane=(i32*)malloc((size_t)(np>0?np:1)*4*sizeof(i32));
+    char *have=(char*)calloc((size_t)(np>0?np:1),1);
+    int i,j,k,count=0,rc=0;
+    for(i=0;i<np&&rc==0;i++)
+    {
+        const i32 *pv=polyverts+(size_t)polys[i*4+3]*6;
+        i32 *pn=polynormals+polys[i*4+3];
+        int e=polys[i*4+2];
+        if(!lto_normal_plane(verts+(size_t)pv[0]*4,verts+(size_t)pv[6]*4,verts+(size_t)pv[12]*4,plane+i*4)){ rc=-1; break; }
+        if(types[i]&1)
+        {
+            int idx=add_tuple(normals,&count,limit,plane+i*4);
+            if(idx<0){ rc=-2; break; }
+            for(j=0;j<=e;j++) pn[j]=idx;
+            have[i]=1;
+        }
+    }
+    for(i=0;i<nv&&rc==0;i++)
+    {
+        i32 n[3]={0,0,0};
+        int num=0;
+        for(j=0;j<np;j++)
+        {
+            if(types[j]&2)
+            {
+                const i32 *pv=polyverts+(size_t)polys[j*4+3]*6;
+                i32 *pn=polynormals+polys[j*4+3];
+                int e=polys[j*4+2];
+                if(!have[j]){ for(k=0;k<=e;k++) pn[k]=0; have[j]=1; }
+                for(k=0;k<=e;k++)
+                    if(pv[k*6]==i)
+                    {
+                        pn[k]=-1;
+                        n[0]=wadd(n[0],plane[j*4]); n[1]=wadd(n[1],plane[j*4+1]); n[2]=wadd(n[2],plane[j*4+2]);
+                        num++;
+                    }
+            }
+        }
+        if(num!=0)
+        {
+            int idx;
+            n[0]/=num; n[1]/=num; n[2]/=num;
+            idx=add_tuple(normals,&count,limit,n);
+            if(idx<0){ rc=-2; break; }
+            for(j=0;j<np;j++)
+                if(types[j]&2)
+                {
+                    i32 *pn=polynormals+polys[j*4+3];
+                    int e=polys[j*4+2];
+                    for(k=0;k<=e;k++) if(pn[k]==-1) pn[k]=idx;
+                }
+        }
+    }
+    free(plane); free(have);
+    return rc<0?rc:count;
+}

@@ -65,6 +65,10 @@ def lib():
         L.lto_shade_polys.restype = C.c_int
         L.lto_shade_polys.argtypes = ([C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p, C.c_int] * 2 + [C.c_void_p, C.c_int]
                                       + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
+        L.lto_normal_plane.restype = C.c_int
+        L.lto_normal_plane.argtypes = [C.c_void_p] * 4
+        L.lto_init_normals.restype = C.c_int
+        L.lto_init_normals.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -233,3 +237,24 @@ def shade_polys(s9, pos, verts, normals, polys, polyverts, polynormals, polyaux,
                                     _p(po), po.shape[0], _p(pv), _p(pn), pv.shape[0], _p(pa), _p(li), li.shape[0],
                                     C.byref(bad))
     return pv, pa, skipped, bad.value
+
+
+def normal_plane(p1, p2, p3):
+    """T_normal_plane -> int32[3], or None for a zero-length normal."""
+    a, b, c, to = _i32(p1), _i32(p2), _i32(p3), np.zeros(3, np.int32)
+    return to if lib().lto_normal_plane(_p(a), _p(b), _p(c), _p(to)) else None
+
+
+def init_normals(verts, polys, types, polyverts, limit=1024):
+    """The normals half of M_init_polygon_object -> (normals int32[nn][3], polynormals
+    int32[records], -2 where a polygon got no m_normals array).  Raises ValueError where the
+    reference stops (zero-length plane normal, list full)."""
+    v, po, ty = _i32(verts).reshape(-1, 4), _i32(polys).reshape(-1, 4), _i32(types).reshape(-1)
+    pv = _i32(polyverts).reshape(-1, 6)
+    normals = np.zeros((limit, 4), np.int32)
+    pn = np.full(pv.shape[0], -2, np.int32)
+    nn = lib().lto_init_normals(_p(v), v.shape[0], _p(po), _p(ty), po.shape[0], _p(pv), _p(normals), limit, _p(pn))
+    if nn < 0:
+        raise ValueError("zero-length plane normal" if nn == -1 else "normal list full")
+    return normals[:nn, :3].copy(), pn
+

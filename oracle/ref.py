@@ -180,3 +180,17 @@ class Ref:
                                   int(pos[0]), int(pos[1]), int(pos[2]), int(ang[0]), int(ang[1]), int(ang[2]),
                                   _p(li), li.shape[0])
         return pv, pa
+
+    def init_object(self, verts, polys, types, polyverts):
+        """the real M_init_polygon_object (normals only; at most 1024 vertices, polygons and
+        normals) -> (normals int32[nn][3], polynormals int32[records], -2 where a polygon got
+        no m_normals array)"""
+        v, po, ty = _i32(verts).reshape(-1, 4).copy(), _i32(polys).reshape(-1, 4), _i32(types).reshape(-1)
+        pv = _i32(polyverts).reshape(-1, 6).copy()
+        assert v.shape[0] <= 1024 and po.shape[0] <= 1024
+        normals = np.zeros((1024, 4), np.int32)
+        pn = np.full(pv.shape[0], -2, np.int32)
+        self.L.ltref_init_object.restype = C.c_int
+        nn = self.L.ltref_init_object(_p(v), v.shape[0], _p(po), _p(ty), _p(pv), po.shape[0], _p(normals), _p(pn))
+        return normals[:nn, :3].copy(), pn
+

@@ -232,6 +232,39 @@ void ltref_scan_polygon(int *tuples,int length,int dim,int *miny,int *maxy,
  }
 }
 
+/* The real M_init_polygon_object (EngPoly.cpp:355-459) without _PAINTER_: normals only.
+ * types[np] = m_type.  normals[1024][4] receives the object's list (three words per
+ * normal are defined), polynormals[*] (laid out like polyverts) the indices of polygons
+ * that got an m_normals array.  Returns m_no_normals. */
+int ltref_init_object(int *verts,int nv,const int *polys,const int *types,int *polyverts,int np,
+                      int *normals,int *polynormals)
+{
+ std::vector<struct M_polygon> store(np);
+ std::vector<struct M_polygon*> ptrs(np);
+ struct M_polygon_object obj;
+ for(int i=0;i<np;i++)
+ {
+  fill_polygon(&store[i],polys,NULL,polyverts,i);
+  store[i].m_type=types[i];
+  ptrs[i]=&store[i];
+ }
+ obj.m_type=M_POLYGON_OBJECT; obj.m_order=NULL;
+ obj.m_no_polygons=np; obj.m_polygons=ptrs.data();
+ obj.m_no_vertices=nv; obj.m_vertices=verts;
+ obj.m_no_normals=0; obj.m_normals=NULL;
+ M_init_polygon_object(&obj);
+ for(int i=0;i<obj.m_no_normals;i++)
+  for(int k=0;k<3;k++) normals[i*4+k]=obj.m_normals[i*T_LNG_VECTOR+k];
+ for(int i=0;i<np;i++)
+  if(store[i].m_normals)
+  {
+   for(int k=0;k<=store[i].m_no_edges;k++) polynormals[polys[i*4+3]+k]=store[i].m_normals[k];
+   free(store[i].m_normals);
+  }
+ free(obj.m_normals);
+ return obj.m_no_normals;
+}
+
 } /* extern "C" */
 
 /* ---- shading pre-pass (EngPoly.cpp:464-493) ---- */

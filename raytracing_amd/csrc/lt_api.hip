@@ -551,8 +551,9 @@ int lt_flush(lt_ctx *c)
         unsigned long long d = s.zero_light_vectors - c->base.zero_light_vectors;
         c->base.zero_light_vectors = s.zero_light_vectors;
         return fail(c, LT_ERR_UNSUPPORTED,
-                    "%llu vertex/point-light pair(s) at zero distance: the reference stops there with 'Found a zero "
-                    "length vector'; that light was left out for that vertex", d);
+                    "%llu zero-length vector(s) -- a point light at a vertex, or a polygon whose first three vertices "
+                    "span no plane: the reference stops there with 'Found a zero length vector'; that light was left "
+                    "out for that vertex, that plane normal is {0,0,0}", d);
     }
     if (s.order_dependent_rows > c->base.order_dependent_rows) {
         unsigned long long d = s.order_dependent_rows - c->base.order_dependent_rows;
@@ -725,6 +726,44 @@ int lt_shade_object(lt_ctx *c, const int32_t s9[9], int32_t x, int32_t y, int32_
     HIPCHK(c, hipMemcpyAsync(polyaux, c->s_aux.p, (size_t)np * 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LT_OK;
+}
+
+int lt_plane_normals_dev(lt_ctx *c, const int32_t *d_verts, int nv, const int32_t *d_polys, int np,
+                         const int32_t *d_polyverts, int npv, int32_t *d_plane_normals)
+{
+    if (!c) return LT_ERR_ARG;
+    if (np < 0 || nv < 0 || npv < 0) return fail(c, LT_ERR_ARG, "lt_plane_normals: negative count");
+    if (np == 0) return LT_OK;
+    if (!d_verts || !d_polys || !d_polyverts || !d_plane_normals) return fail(c, LT_ERR_ARG, "lt_plane_normals: NULL array");
+    int rc = use_device(c);
+    if (rc) return rc;
+    launch_plane_normals(c->stream, d_verts, nv, d_polys, np, d_polyverts, npv, d_plane_normals, c->status);
+    HIPCHK(c, hipGetLastError());
+    return LT_OK;
+}
+
+int lt_plane_normals(lt_ctx *c, const int32_t *verts, int nv, const int32_t *polys, int np,
+                     const int32_t *polyverts, int npv, int32_t *plane_normals)
+{
+    if (!c) return LT_ERR_ARG;
+    if (np == 0) return LT_OK;
+    if (np < 0 || nv <= 0 || npv <= 0 || !verts || !polys || !polyverts || !plane_normals)
+        return fail(c, LT_ERR_ARG, "lt_plane_normals: bad argument");
+    int rc = lt_flush(c);                          // the staging arrays are free, earlier reports are out
+    if (rc) return rc;
+    if ((rc = ensure(c, c->s_verts, (size_t)nv * 16))) return rc;
+    if ((rc = ensure(c, c->s_polys, (size_t)np * 16))) return rc;
+    if ((rc = ensure(c, c->s_pv, (size_t)npv * 24))) return rc;
+    if ((rc = ensure(c, c->s_normals, (size_t)np * 16))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_verts.p, verts, (size_t)nv * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_polys.p, polys, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_pv.p, polyverts, (size_t)npv * 24, hipMemcpyHostToDevice, c->stream));
+    if ((rc = lt_plane_normals_dev(c, (const int *)c->s_verts.p, nv, (const int *)c->s_polys.p, np, (const int *)c->s_pv.p, npv,
+                                   (int *)c->s_normals.p)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(plane_normals, c->s_normals.p, (size_t)np * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return lt_flush(c);                            // reports a zero-length normal
 }
 
 int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts, int nv, const int32_t *d_polys,

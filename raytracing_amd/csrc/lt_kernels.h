@@ -24,9 +24,11 @@ struct PrimHdr { int yy, xx, colour, meta; };
 //   {x1|y1<<16, x2|y2<<16, Zstart, Zinc, start[1..NA-1], inc[1..NA-1], padding}
 // Zstart = Z1<<16, Zinc = ((Z2-Z1)<<16)/L; the other values as in GraphicsPoly.cpp:171-176.
 // NA = 1 (flat: 4 ints), 4 (shaded: 12 ints), 6 (textured: 16 ints).  The depth pass
-// reads only the first piece.  The pool is laid out [edge][piece][polygon] in 16-byte
-// units: piece q of edge k of polygon p is unit (k*(ESZ/4) + q)*np + p, so the lanes of a
-// setup wave (consecutive polygons) store adjacent pieces, and no allocation is needed.
+// reads only the first piece.  The pool holds, per output slot, one record of
+// 4 + 3*(pieces-1) 16-byte units: {copy of the header, first piece of edges 0, 1, 2, the
+// other pieces of edge 0, of edge 1, of edge 2}, so a triangle's depth data is one 64-byte
+// run and the whole triangle one run of 64 / 160 / 208 bytes.  Edges 3 and up (clipped
+// polygons) follow the records as planes [edge][piece][slot].  No allocation is needed.
 __host__ __device__ constexpr int edge_ints(int na) { return na == 1 ? 4 : (na == 4 ? 12 : 16); }
 
 // Constants of G_prp_textured_polygon for one polygon (GraphicsPoly.cpp:563-578):
@@ -127,6 +129,8 @@ struct ShadeArgs {
     int lights[MAX_LIGHTS][8];       // {type, px,py,pz,pw, red,green,blue}
     Status *status;
 };
+void launch_plane_normals(hipStream_t s, const int *verts, int nv, const int *polys, int np, const int *polyverts,
+                          int npv, int *out, Status *status);
 void launch_shade(hipStream_t s, const ShadeArgs &a);
 
 void launch_transform(hipStream_t s, const int *m12_dev, const int *from, int *to, int n);

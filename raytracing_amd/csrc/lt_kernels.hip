@@ -164,6 +164,47 @@ __device__ __forceinline__ int scalar_product(const int (&a)[3], const int (&b)[
     return (int)(((long long)a[0] * b[0] + (long long)a[1] * b[1] + (long long)a[2] * b[2]) >> 7);
 }
 
+// T_normal_plane (TransLn.cpp:150-171) for every polygon of an object, as the first loop of
+// M_init_polygon_object runs it (EngPoly.cpp:392-398): the unit normal, 7 fraction bits, of
+// the plane through the vertices of the polygon's first three records.  The products of the
+// vector product wrap in 32 bits like the reference's int arithmetic.  One polygon per
+// lane; out[poly] = {nx, ny, nz, 0}.  A zero-length product (where the reference stops with
+// "Found a zero length vector") or records/indices out of range give {0, 0, 0, 0} and are
+// counted.
+__global__ void __launch_bounds__(256) plane_normals_kernel(const int *__restrict__ verts, int nv,
+                                                            const int *__restrict__ polys, int np,
+                                                            const int *__restrict__ polyverts, int npv,
+                                                            int4 *__restrict__ out, Status *status)
+{
+    const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    bool zero = false;
+    if (poly < np) {
+        const int4 pd = ((const int4 *)polys)[poly];
+        const int first = pd.w;
+        int4 r = make_int4(0, 0, 0, 0);
+        zero = true;
+        if (first >= 0 && (long long)first + 3 <= (long long)npv) {
+            const int i0 = polyverts[(size_t)first * 6], i1 = polyverts[(size_t)(first + 1) * 6], i2 = polyverts[(size_t)(first + 2) * 6];
+            if ((unsigned)i0 < (unsigned)nv && (unsigned)i1 < (unsigned)nv && (unsigned)i2 < (unsigned)nv) {
+                const int4 a = ((const int4 *)verts)[i0], b = ((const int4 *)verts)[i1], c = ((const int4 *)verts)[i2];
+                const int v[3] = {wsub(b.x, a.x), wsub(b.y, a.y), wsub(b.z, a.z)};
+                const int w[3] = {wsub(c.x, a.x), wsub(c.y, a.y), wsub(c.z, a.z)};
+                const int n[3] = {wsub(wmul(v[1], w[2]), wmul(v[2], w[1])), wsub(wmul(v[2], w[0]), wmul(v[0], w[2])),
+                                  wsub(wmul(v[0], w[1]), wmul(v[1], w[0]))};
+                const long long lng = t_norm(n);
+                if (lng != 0) {
+                    r = make_int4(unit_component(n[0], lng), unit_component(n[1], lng), unit_component(n[2], lng), 0);
+                    zero = false;
+                }
+            }
+        }
+        out[poly] = r;
+    }
+    const unsigned long long m = __ballot(zero);
+    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1))
+        atomicAdd(&status[blockIdx.x % STATUS_SLOTS].zero_light_vectors, (unsigned long long)__popcll(m));
+}
+
 // M_shade_polygon over M_shade_vertex (EngBase.cpp:220-364): one polygon per lane; every
 // record of the polygon gets its R,G,B from the light list, the polygon its flat
 // illumination (the truncated mean over its n_edges+1 records).  Vertices and normals are
@@ -1955,6 +1996,14 @@ void launch_shade(hipStream_t s, const ShadeArgs &a)
 {
     if (a.np <= 0) return;
     hipLaunchKernelGGL(shade_kernel, dim3((a.np + 255) / 256), dim3(256), 0, s, a);
+}
+
+void launch_plane_normals(hipStream_t s, const int *verts, int nv, const int *polys, int np, const int *polyverts,
+                          int npv, int *out, Status *status)
+{
+    if (np <= 0) return;
+    hipLaunchKernelGGL(plane_normals_kernel, dim3((np + 255) / 256), dim3(256), 0, s, verts, nv, polys, np, polyverts, npv,
+                       (int4 *)out, status);
 }
 
 void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)

@@ -162,6 +162,19 @@ class Context:
                                          _p(li), li.shape[0]))
         return pv, pa
 
+    def plane_normals_dev(self, d_verts, d_polys, d_polyverts, d_out):
+        """T_normal_plane of every polygon's first three records (the first loop of
+        M_init_polygon_object) on device arrays: d_out int32[np][4] = {nx, ny, nz, 0}."""
+        self._chk(self.L.lt_plane_normals_dev(self.h_ctx, _dp(d_verts), d_verts.shape[0], _dp(d_polys), d_polys.shape[0],
+                                              _dp(d_polyverts), d_polyverts.shape[0], _dp(d_out)))
+
+    def plane_normals(self, verts, polys, polyverts):
+        """host arrays -> int32[np][4]; raises where the reference stops (zero-length normal)"""
+        v, po, pv = _i32(verts).reshape(-1, 4), _i32(polys).reshape(-1, 4), _i32(polyverts).reshape(-1, 6)
+        out = np.zeros((po.shape[0], 4), np.int32)
+        self._chk(self.L.lt_plane_normals(self.h_ctx, _p(v), v.shape[0], _p(po), po.shape[0], _p(pv), pv.shape[0], _p(out)))
+        return out
+
     def submit_object(self, verts, polys, polyverts, render_type, log_focus, polyaux=None, matrix=None,
                       force_linear=0, max_edges=0):
         m = _i32(IDENTITY if matrix is None else matrix)

@@ -331,6 +331,85 @@ void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *
     if (poly->m_no_edges > q_max_edges) q_max_edges = poly->m_no_edges;
 }
 
+// The list of normals under construction: MI_add_tuple (EngPoly.cpp:46-63) compares X Y Z
+// and appends what it has not seen.
+static int add_tuple(std::vector<int> &list, const int *t)
+{
+    const int n = (int)(list.size() / T_LNG_VECTOR);
+    for (int i = 0; i < n; i++)
+        if (list[(size_t)i * T_LNG_VECTOR] == t[0] && list[(size_t)i * T_LNG_VECTOR + 1] == t[1] &&
+            list[(size_t)i * T_LNG_VECTOR + 2] == t[2])
+            return i;
+    if (n >= M_MAX_OBJECT_VERTICES) HW_error((char *)"(Engine) Not enough internal storage for vertices.\n");
+    const int rec[T_LNG_VECTOR] = {t[0], t[1], t[2], 0};
+    list.insert(list.end(), rec, rec + T_LNG_VECTOR);
+    return n;
+}
+
+// EngPoly.cpp:355-459 with a depth buffer (no BSP ordering): the plane normal of every
+// polygon is computed on the GPU (lt_plane_normals); the list handling -- planar polygons
+// share one index per distinct normal, the vertices of curved polygons get the truncated
+// mean of the plane normals of the curved polygons that use them -- follows the
+// reference's order of insertion, so the indices come out the same.  m_normals arrays are
+// malloc'ed as in the reference (the caller owns them).
+void M_init_polygon_object(struct M_polygon_object *object)
+{
+    need_ctx();
+    const int np = object->m_no_polygons;
+    std::vector<int32_t> polys, pv;
+    for (int i = 0; i < np; i++) {
+        const M_polygon *p = object->m_polygons[i];
+        const int32_t hd[4] = {p->m_colour, -1, p->m_no_edges, (int32_t)(pv.size() / 6)};
+        polys.insert(polys.end(), hd, hd + 4);
+        pv.insert(pv.end(), p->m_vertices, p->m_vertices + (size_t)(p->m_no_edges + 1) * M_LNG_POLYGON_VERTEX);
+    }
+    std::vector<int32_t> plane((size_t)(np > 0 ? np : 1) * 4);
+    if (np > 0)     // a zero-length normal stops the reference (TransLn.cpp:166); chk() stops here with the library's message
+        chk(lt_plane_normals(g_ctx, object->m_vertices, object->m_no_vertices, polys.data(), np, pv.data(), (int)(pv.size() / 6),
+                             plane.data()));
+    std::vector<int> list;
+    for (int i = 0; i < np; i++) {
+        M_polygon *p = object->m_polygons[i];
+        if (p->m_type & M_PLANNAR) {
+            p->m_normals = (int *)malloc(sizeof(int) * (p->m_no_edges + 1));
+            if (p->m_normals == nullptr) HW_error((char *)"(Engine) Not enough memory.\n");
+            const int idx = add_tuple(list, &plane[(size_t)i * 4]);
+            for (int j = 0; j <= p->m_no_edges; j++) p->m_normals[j] = idx;
+        }
+    }
+    for (int i = 0; i < object->m_no_vertices; i++) {
+        int n[3] = {0, 0, 0}, num = 0;
+        for (int j = 0; j < np; j++) {
+            M_polygon *p = object->m_polygons[j];
+            if (!(p->m_type & M_CURVED)) continue;
+            if (p->m_normals == nullptr) {
+                p->m_normals = (int *)calloc((size_t)p->m_no_edges + 1, sizeof(int));
+                if (p->m_normals == nullptr) HW_error((char *)"(Engine) Not enough memory.\n");
+            }
+            for (int k = 0; k <= p->m_no_edges; k++)
+                if (p->m_vertices[k * M_LNG_POLYGON_VERTEX] == i) {
+                    p->m_normals[k] = -1;
+                    for (int c = 0; c < 3; c++) n[c] = (int)((unsigned)n[c] + (unsigned)plane[(size_t)j * 4 + c]);
+                    num++;
+                }
+        }
+        if (num != 0) {
+            n[0] /= num; n[1] /= num; n[2] /= num;
+            const int idx = add_tuple(list, n);
+            for (int j = 0; j < np; j++) {
+                M_polygon *p = object->m_polygons[j];
+                if (!(p->m_type & M_CURVED)) continue;
+                for (int k = 0; k <= p->m_no_edges; k++)
+                    if (p->m_normals[k] == -1) p->m_normals[k] = idx;
+            }
+        }
+    }
+    object->m_no_normals = (int)(list.size() / T_LNG_VECTOR);
+    object->m_normals = (int *)malloc(sizeof(int) * (list.size() ? list.size() : 1));
+    if (object->m_normals == nullptr) HW_error((char *)"(Engine) Not enough memory.\n");
+    memcpy(object->m_normals, list.data(), sizeof(int) * list.size());
+}
+
 void M_shade_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam,
                             int no_lights, struct M_light **lights)
 {

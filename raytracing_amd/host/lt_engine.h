@@ -116,6 +116,11 @@ struct M_light {
     int m_red, m_green, m_blue;
 };
 
+// EngPoly.cpp:355-459 (no BSP ordering with a depth buffer): gives every M_PLANNAR / M_CURVED
+// polygon its m_normals indices and the object its list of normals; m_normals must be NULL
+// on entry, as in the reference.
+void M_init_polygon_object(struct M_polygon_object *object);
+
 // EngPoly.cpp:464-493: every polygon's vertex records receive their R,G,B and the polygon
 // its flat m_red/m_green/m_blue, computed on the GPU and written back before the call returns.
 void M_shade_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam,

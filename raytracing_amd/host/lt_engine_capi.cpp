@@ -3,6 +3,7 @@
 // the flat scene arrays and calls the mirror exactly as a reference-style program would.
 #include "lt_engine.h"
 #include <stddef.h>
+#include <stdlib.h>
 #include <vector>
 
 extern "C" {
@@ -84,6 +85,35 @@ void lte_shade_object(int *verts, int nv, int *normals, int nn, const int *polys
     obj.m_no_normals = nn; obj.m_normals = normals;
     M_shade_polygon_object(&obj, x, y, z, alp, bet, gam, nl, lp.data());
     for (int i = 0; i < np; i++) { aux[i * 4] = store[i].m_red; aux[i * 4 + 1] = store[i].m_green; aux[i * 4 + 2] = store[i].m_blue; }
+}
+
+// M_init_polygon_object on one object; types[np] = m_type.  normals[1024][4] and
+// polynormals[records] (entries of polygons without an m_normals array are left alone)
+// are filled; returns m_no_normals.
+int lte_init_object(int *verts, int nv, const int *polys, const int *types, int *pv, int np, int *normals, int *pn)
+{
+    std::vector<M_polygon> store(np);
+    std::vector<M_polygon *> ptrs(np);
+    for (int i = 0; i < np; i++) {
+        fill(&store[i], g_texs, polys, nullptr, pv, i);
+        store[i].m_type = types[i];
+        store[i].m_normals = nullptr;
+        ptrs[i] = &store[i];
+    }
+    M_polygon_object obj;
+    obj.m_type = M_POLYGON_OBJECT; obj.m_order = nullptr;
+    obj.m_no_polygons = np; obj.m_polygons = ptrs.data();
+    obj.m_no_vertices = nv; obj.m_vertices = verts;
+    obj.m_no_normals = 0; obj.m_normals = nullptr;
+    M_init_polygon_object(&obj);
+    for (int i = 0; i < obj.m_no_normals * 4; i++) normals[i] = obj.m_normals[i];
+    for (int i = 0; i < np; i++)
+        if (store[i].m_normals) {
+            for (int k = 0; k <= store[i].m_no_edges; k++) pn[polys[i * 4 + 3] + k] = store[i].m_normals[k];
+            free(store[i].m_normals);
+        }
+    free(obj.m_normals);
+    return obj.m_no_normals;
 }
 
 // the transform, then one M_render_polygon call per polygon (as EngPoly.cpp:512-523 does)

@@ -339,3 +339,48 @@ def gen_shading_case(n_polys: int, seed: int, n_verts: int = 0, n_normals: int =
                        [4, 40, -90, 80, 0, 90, 100, 110],
                        [2, 70000 if far_light else 900, 3, 9, 0, 255, 255, 255]], np.int32)
     return dict(verts=verts, normals=normals, polys=polys, polyverts=pv, polynormals=pn, lights=lights)
+
+
+def gen_sphere_object(n_long: int = 16, n_lat: int = 8, radius: int = 300, centre=(0, 0, 0), with_quad: bool = True):
+    """A closed lat/long sphere of M_CURVED triangles over shared vertices (two poles and
+    n_lat-1 rings of n_long vertices) and, optionally, one M_PLANNAR quad below it: the kind
+    of object M_init_polygon_object gives normals to.
+    -> dict(verts int32[nv][4], polys int32[np][4], types int32[np], polyverts int32[*][6])"""
+    cx, cy, cz = centre
+    vs = [(cx, cy - radius, cz)]
+    for i in range(1, n_lat):
+        th = np.pi * i / n_lat
+        for j in range(n_long):
+            ph = 2 * np.pi * j / n_long
+            vs.append((cx + int(round(radius * np.sin(th) * np.cos(ph))), cy - int(round(radius * np.cos(th))),
+                       cz + int(round(radius * np.sin(th) * np.sin(ph)))))
+    vs.append((cx, cy + radius, cz))
+    south = len(vs) - 1
+
+    def ring(i, j):
+        return 1 + (i - 1) * n_long + (j % n_long)
+
+    faces, types = [], []
+    for j in range(n_long):
+        faces.append((0, ring(1, j + 1), ring(1, j)))
+        faces.append((south, ring(n_lat - 1, j), ring(n_lat - 1, j + 1)))
+        for i in range(1, n_lat - 1):
+            faces.append((ring(i, j), ring(i, j + 1), ring(i + 1, j + 1)))
+            faces.append((ring(i, j), ring(i + 1, j + 1), ring(i + 1, j)))
+    types += [2] * len(faces)
+    if with_quad:
+        b = len(vs)
+        y = cy + radius + 30
+        vs += [(cx - 2 * radius, y, cz + 2 * radius), (cx + 2 * radius, y, cz + 2 * radius),
+               (cx + 2 * radius, y, cz - 2 * radius), (cx - 2 * radius, y, cz - 2 * radius)]
+        faces.append((b, b + 1, b + 2, b + 3))
+        types.append(1)
+    verts = np.zeros((len(vs), 4), np.int32)
+    verts[:, :3] = np.array(vs, np.int32)
+    recs, polys = [], []
+    for f in faces:
+        polys.append((0x00FFFFFF, -1, len(f), len(recs)))
+        for idx in list(f) + [f[0]]:
+            recs.append((idx, 0, 0, 0, 0, 0))
+    return dict(verts=verts, polys=np.array(polys, np.int32), types=np.array(types, np.int32),
+                polyverts=np.array(recs, np.int32))

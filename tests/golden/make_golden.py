@@ -326,6 +326,37 @@ def shade_kats():
     return out
 
 
+NORMAL_CASES = [dict(n_long=16, n_lat=8, radius=300, centre=(0, 0, 0), mix=0),
+                dict(n_long=12, n_lat=6, radius=2500, centre=(40, -900, 7000), mix=1),
+                dict(n_long=20, n_lat=10, radius=90, centre=(-5, 3, 200), mix=2)]
+
+
+def normal_case_types(types, mix):
+    """m_type per polygon of a normals case: the generator's, or with planar|curved, typeless
+    and planar polygons mixed in"""
+    ty = types.copy()
+    if mix >= 1:
+        ty[::5] = 3
+        ty[1::7] = 0
+    if mix >= 2:
+        ty[2::3] = 1
+    return ty
+
+
+def normals_kats():
+    """Object set-up vectors: the reference's M_init_polygon_object on generated spheres."""
+    r = R.Ref(160, 120)
+    out = {}
+    for k, c in enumerate(NORMAL_CASES):
+        ob = S.gen_sphere_object(c["n_long"], c["n_lat"], c["radius"], c["centre"])
+        ty = normal_case_types(ob["types"], c["mix"])
+        n, pn = r.init_object(ob["verts"], ob["polys"], ty, ob["polyverts"])
+        out[f"normals_{k}"] = n
+        out[f"polynormals_{k}"] = pn
+    out["n_cases"] = len(NORMAL_CASES)
+    return out
+
+
 def bench_frame():
     """The benchmark's own frame (1M Gouraud triangles at 1080p), drawn by the reference build."""
     sc = S.gen_c2(1_000_000, 1920, 1080, 10, radius=8)
@@ -340,6 +371,7 @@ def bench_frame():
 def main():
     json.dump(bench_frame(), open(os.path.join(HERE, "bench_frame.json"), "w"), indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "shade_kats.npz"), **shade_kats())
+    np.savez_compressed(os.path.join(HERE, "normals_kats.npz"), **normals_kats())
     if not os.path.isdir(REFDIR):
         raise SystemExit("needs /root/reference (run in the build container)")
     np.savez_compressed(os.path.join(HERE, "stage_kats.npz"), **stage_kats())
