@@ -294,17 +294,14 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     }
     launch_binning(gs, (const PrimHdr *)w.hdr.p, np, c->tiles_x, c->ntiles, (unsigned *)w.tcount.p,
                    (unsigned *)w.toffset.p, (unsigned *)w.tcursor.p, (unsigned *)w.list.p, capacity,
-                   screen ? nullptr : sa.queue_count, c->status, scan_ev, fused);
+                   screen ? nullptr : sa.queue_count, c->status, scan_ev, fused, c->pipelined ? w.geom_done : nullptr);
     if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
     if (timed(c, 3)) {
         lt_ctx::Span sp{3, scan_idx, 0};
         c->spans.push_back(sp);
         if ((rc = stage_end(c, 3, gs))) return rc;
     }
-    if (c->pipelined) {
-        HIPCHK(c, hipEventRecord(w.geom_done, gs));
-        HIPCHK(c, hipStreamWaitEvent(rs, w.geom_done, 0));
-    }
+    if (c->pipelined) HIPCHK(c, hipStreamWaitEvent(rs, w.geom_done, 0));      // the scatter's completion
 
     RasterArgs ra{};
     ra.hdr = (const PrimHdr *)w.hdr.p; ra.edges = (const int *)w.edges.p;
@@ -320,15 +317,27 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     ra.force_order = (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0;
     ra.band_y0 = c->band_y0; ra.band_y1 = c->band_y1;
     ra.status = c->status;
-    if ((rc = stage_begin(c, 4, rs))) return rc;
-    launch_raster(rs, na, ra);
-    if (dim == 8 && c->order_mode != LT_ORDER_NEVER) HIPCHK(c, launch_ordered(rs, ra));
-    if ((rc = stage_end(c, 4, rs))) return rc;
-    HIPCHK(c, hipGetLastError());
-    if (c->pipelined) {
-        HIPCHK(c, hipEventRecord(w.raster_done, rs));
-        w.in_use = true;
+    // The fill's events are its own dispatch's where no other kernel follows it: its start
+    // and end for the stage timing, else its completion as this work set's "free" signal.
+    const bool ordered_follows = dim == 8 && c->order_mode != LT_ORDER_NEVER;
+    if (ordered_follows) {
+        if ((rc = stage_begin(c, 4, rs))) return rc;
+        launch_raster(rs, na, ra, nullptr, nullptr);
+        HIPCHK(c, launch_ordered(rs, ra));
+        if ((rc = stage_end(c, 4, rs))) return rc;
+        if (c->pipelined) HIPCHK(c, hipEventRecord(w.raster_done, rs));
+    } else if (timed(c, 4)) {
+        lt_ctx::Span sp{4, 0, 0};
+        if ((rc = new_event(c, (hipStream_t)-1, &sp.begin))) return rc;
+        if ((rc = new_event(c, (hipStream_t)-1, &sp.end))) return rc;
+        c->spans.push_back(sp);
+        launch_raster(rs, na, ra, c->ev_pool[sp.begin], c->ev_pool[sp.end]);
+        if (c->pipelined) HIPCHK(c, hipEventRecord(w.raster_done, rs));
+    } else {
+        launch_raster(rs, na, ra, nullptr, c->pipelined ? w.raster_done : nullptr);
     }
+    HIPCHK(c, hipGetLastError());
+    if (c->pipelined) w.in_use = true;
     c->batch_no++;
     if (c->profiling && (c->batch_no - 1) % c->profile_every == 0) c->timed_batches++;
 

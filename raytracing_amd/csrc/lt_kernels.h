@@ -2,6 +2,7 @@
 // and the C-ABI (lt_api.cpp side of the same library).  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace lt {
@@ -138,8 +139,8 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
 // tile lists: count -> exclusive scan -> scatter (count must be zero before the call)
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted);
-void launch_raster(hipStream_t s, int na, const RasterArgs &a);
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done);
+void launch_raster(hipStream_t s, int na, const RasterArgs &a, hipEvent_t start, hipEvent_t stop);
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a);   // textured batches only
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 

@@ -2038,7 +2038,7 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
 
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted)
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done)
 {
     const bool lds = ntiles <= BIN_MAX_TILES;
     if (np > 0 && !counted) {
@@ -2048,17 +2048,21 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int 
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, cursor, ntiles, capacity, queue_count, status);
     if (after_scan) (void)hipEventRecord(after_scan, s);
     if (np > 0) {
-        if (lds) hipLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity);
-        else hipLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, tiles_x, (const unsigned *)offset, cursor, list, capacity);
+        // `done` (may be null) is the scatter's own completion (see launch_raster)
+        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, nullptr, done, 0, hdr, np, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity);
+        else hipExtLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nullptr, done, 0, hdr, np, tiles_x, (const unsigned *)offset, cursor, list, capacity);
     }
 }
 
-void launch_raster(hipStream_t s, int na, const RasterArgs &a)
+// `start` / `stop` (either may be null) ride on the kernel's own dispatch: they take its
+// start and completion without a marker of their own in the stream, which would hold the
+// stream for a few microseconds each.
+void launch_raster(hipStream_t s, int na, const RasterArgs &a, hipEvent_t start, hipEvent_t stop)
 {
     dim3 g(a.tiles_x * a.tiles_y), b(RASTER_THREADS);
-    if (na == 1) hipLaunchKernelGGL((raster_kernel<1>), g, b, 0, s, a);
-    else if (na == 4) hipLaunchKernelGGL((raster_kernel<4>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((raster_kernel<6>), g, b, 0, s, a);
+    if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1>), g, b, 0, s, start, stop, 0, a);
+    else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4>), g, b, 0, s, start, stop, 0, a);
+    else hipExtLaunchKernelGGL((raster_kernel<6>), g, b, 0, s, start, stop, 0, a);
 }
 
 int ordered_band_rows(int W, int H)
