@@ -41,7 +41,8 @@ extern "C" {
 
 typedef struct lt_ctx lt_ctx;
 
-/* rendering types: M_FLAT / M_SHADED / M_TEXTURED, Engine.h:81-83 */
+/* rendering types: M_WIRE / M_FLAT / M_SHADED / M_TEXTURED, Engine.h:80-83 */
+#define LT_WIRE      1
 #define LT_FLAT      2
 #define LT_SHADED    4
 #define LT_TEXTURED  8
@@ -193,6 +194,20 @@ int lt_shade_object(lt_ctx *ctx, const int32_t s9[9], int32_t x, int32_t y, int3
                     const int32_t *polynormals, int npv, int32_t *polyaux,
                     const lt_light *lights, int nlights);
 
+/* G_line (GraphicsBase.cpp:165-253) for n lines in draw order: lines[i] = {x1, y1, z1, x2, y2,
+ * z2, lit colour, 0} with projected end points (what T_perspective returns) and the colour
+ * CL_light(colour, red, green, blue) of the reference's arguments.  Each line is clipped to
+ * the screen (C_line_x_clipping, C_line_y_clipping) and walked point by point; a point is
+ * drawn where its depth is less than the depth buffer's, which lines do not write; where
+ * lines overlap the later one stays.  The reference clips a line with dimension 2, so the
+ * depth of a clipped end point is read from the third word of a static store of the clipper
+ * (Clipp2D.cpp:99-104, 132, 150): 0 in a program that draws only wireframes, a leftover of
+ * the polygon clipper's calls after filled polygons.  This library uses 0.  Lines are
+ * drawn after everything submitted before them and before everything submitted after.
+ * The device array must be 16-byte aligned. */
+int lt_submit_lines_dev(lt_ctx *ctx, const int32_t *d_lines, int n);
+int lt_submit_lines(lt_ctx *ctx, const int32_t *lines, int n);
+
 /* The plane normals of M_init_polygon_object (EngPoly.cpp:392-398): for every polygon,
  * T_normal_plane (TransLn.cpp:150-171) of the vertices of its first three records:
  * d_plane_normals[p] = {nx, ny, nz, 0}, unit length scaled by 1<<7.  These are the m_normals
@@ -213,7 +228,9 @@ int lt_plane_normals(lt_ctx *ctx, const int32_t *verts, int nv, const int32_t *p
  * the host has built the matrix (T_set_self_rotation + T_cancatinate_self_world):
  * transform, then per polygon what M_render_polygon does (EngBase.cpp:379-552) --
  * tuples, view-volume test, near-plane clip, perspective, back-face cull, screen
- * clip, edge scan, span fill with depth test.  render_type is what M_init_rendering
+ * clip, edge scan, span fill with depth test; with LT_WIRE (EngBase.cpp:393-431) the
+ * edges of the near-clipped polygon are drawn as lines (see lt_submit_lines; polyaux gives
+ * m_red, m_green, m_blue, zeros without it).  render_type is what M_init_rendering
  * set; log_focus what M_set_camera set; force_linear is M_force_linear_tmapping.
  * max_edges bounds no_edges over the batch (0 = 15).  m == NULL means the vertices are
  * already in view space (the M_render_polygon level, EngBase.cpp:379).  Pointers are

@@ -695,6 +695,53 @@ static void construct_tuples(const i32 *rec,i32 *to,const i32 *verts,int dim,int
     }
 }
 
+/* The two clips of G_line (GraphicsBase.cpp:191-193): C_line_x_clipping / C_line_y_clipping
+ * with dimension 2, so only X and Y of an end point that a clipper moves are computed; the
+ * pointer then refers to one of the clipper's static stores (Clipp2D.cpp:99-104,132,150)
+ * and the depth read through it is whatever that store's third word holds.  In a program
+ * that draws only wireframes those words are never written and stay 0 (static storage);
+ * after filled polygons they hold leftovers of the polygon clipper's calls.  This
+ * restatement, like the HIP path, uses 0. */
+static int clip_line_xy(i32 *v1,i32 *v2,int axis,i32 bmax)
+{
+    i32 a[2]={v1[0],v1[1]},b[2]={v2[0],v2[1]},o1[2],o2[2];
+    int moved,swap=!(v1[axis]<v2[axis]);
+    int m1=swap?(v1[axis]>=bmax):(v1[axis]<=0);
+    int m2=swap?(v2[axis]<=0):(v2[axis]>=bmax);
+    if(!clip_line(a,b,2,axis,0,bmax,1,o1,o2,&moved)) return 0;
+    v1[0]=o1[0]; v1[1]=o1[1]; if(m1) v1[2]=0;
+    v2[0]=o2[0]; v2[1]=o2[1]; if(m2) v2[2]=0;
+    return 1;
+}
+
+/* G_line, GraphicsBase.cpp:165-253 (_RGB_, _Z_BUFFER_): depth is tested but not written. */
+void lto_g_line(lto_ctx *c,const i32 *vertex1,const i32 *vertex2,i32 colour,i32 r,i32 g,i32 b)
+{
+    i32 v1[3]={vertex1[0],vertex1[1],vertex1[2]},v2[3]={vertex2[0],vertex2[1],vertex2[2]};
+    i32 hw=lto_cl_light(colour,r,g,b);
+    i32 dx,dy,long_d,short_d,d,add_dh,add_dl,cur_z,inc_z=0;
+    int inc_xh,inc_yh,inc_xl,inc_yl,x,y,i;
+    if(!clip_line_xy(v1,v2,0,c->w-1)) return;
+    if(!clip_line_xy(v1,v2,1,c->h-1)) return;
+    dx=v2[0]-v1[0]; dy=v2[1]-v1[1];
+    if(dx<0){ dx=-dx; inc_xh=-1; inc_xl=-1; } else { inc_xh=1; inc_xl=1; }
+    if(dy<0){ dy=-dy; inc_yh=-1; inc_yl=-1; } else { inc_yh=1; inc_yl=1; }
+    if(dx>dy){ long_d=dx; short_d=dy; inc_yl=0; } else { long_d=dy; short_d=dx; inc_xl=0; }
+    d=2*short_d-long_d; add_dl=2*short_d; add_dh=2*(short_d-long_d);
+    x=v1[0]; y=v1[1];
+    cur_z=v1[2];
+    if(long_d!=0) inc_z=tdiv(wsub(v2[2],cur_z),long_d);
+    for(i=0;i<=long_d;i++)
+    {
+        size_t pos=(size_t)y*c->w+x;
+        c->fragments++;
+        if(cur_z<c->zbuf[pos]) c->cbuf[pos]=hw;
+        if(d>=0){ d+=add_dh; x+=inc_xh; y+=inc_yh; }
+        else    { d+=add_dl; x+=inc_xl; y+=inc_yl; }
+        cur_z=wadd(cur_z,inc_z);
+    }
+}
+
 /* M_render_polygon, EngBase.cpp:379-552, for one polygon of the flat scene layout.
  * polys[i] = {colour, texture handle or -1, no_edges, first};
  * polyaux[i] = {m_red, m_green, m_blue, m_type | log_texture_space_size<<8}. */
@@ -711,8 +758,8 @@ static void render_polygon(lto_ctx *c,const i32 *viewverts,const i32 *poly,const
     c->polys_in++;
     if(number+1>LTO_MAX_TUPLES){ c->overflow++; return; }
     if(kind==LTO_M_TEXTURED&&poly[1]<0) kind=LTO_M_SHADED;      /* EngBase.cpp:470,518-522 */
-    if(kind==LTO_M_FLAT) dim=3; else if(kind==LTO_M_SHADED) dim=6; else if(kind==LTO_M_TEXTURED) dim=8;
-    else { c->unsupported++; return; }                          /* M_WIRE: G_line is outside this path */
+    if(kind==LTO_M_FLAT||kind==LTO_M_WIRE) dim=3; else if(kind==LTO_M_SHADED) dim=6; else if(kind==LTO_M_TEXTURED) dim=8;
+    else { c->unsupported++; return; }
 
     construct_tuples(rec,original1,viewverts,dim,number+1,mn,mx);
     if((cnd=lto_volume_clipping(mn,mx))==0) return;
@@ -730,7 +777,13 @@ static void render_polygon(lto_ctx *c,const i32 *viewverts,const i32 *poly,const
     lto_perspective(c,clipped,persp,dim,number+1,c->log_focus);
     if(!lto_normal_z_negative(persp,persp+dim,persp+2*dim)) return;
     c->polys_drawn++;
-    if(kind==LTO_M_FLAT)
+    if(kind==LTO_M_WIRE)                                         /* EngBase.cpp:416-428 */
+    {
+        int i;
+        for(i=0;i<number;i++)
+            lto_g_line(c,persp+i*3,persp+(i+1)*3,poly[0],aux?aux[0]:0,aux?aux[1]:0,aux?aux[2]:0);
+    }
+    else if(kind==LTO_M_FLAT)
         lto_flat_polygon(c,persp,number,poly[0],aux?aux[0]:0,aux?aux[1]:0,aux?aux[2]:0);
     else if(kind==LTO_M_SHADED)
         lto_shaded_polygon(c,persp,number,poly[0]);

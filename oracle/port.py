@@ -65,6 +65,8 @@ def lib():
         L.lto_shade_polys.restype = C.c_int
         L.lto_shade_polys.argtypes = ([C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p, C.c_int] * 2 + [C.c_void_p, C.c_int]
                                       + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
+        L.lto_g_line.restype = None
+        L.lto_g_line.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4
         L.lto_normal_plane.restype = C.c_int
         L.lto_normal_plane.argtypes = [C.c_void_p] * 4
         L.lto_init_normals.restype = C.c_int
@@ -171,6 +173,11 @@ class Oracle:
         t = _i32(tuples).reshape(-1, 8)
         O, u, v = _i32(O), _i32(u), _i32(v)
         self.L.lto_g_prp_polygon(self.c, _p(t), t.shape[0] - 1, _p(O), _p(u), _p(v), tex, log_scale, log_focus)
+
+    def g_line(self, v1, v2, colour, r=0, g=0, b=0):
+        """G_line on projected {X, Y, Z} end points"""
+        a, bb = _i32(v1), _i32(v2)
+        self.L.lto_g_line(self.c, _p(a), _p(bb), int(colour), int(r), int(g), int(b))
 
     def render_polys(self, viewverts, polys, polyaux, polyverts, render_type, log_focus, force_linear=0):
         vv, po, pv = _i32(viewverts), _i32(polys), _i32(polyverts)

@@ -194,3 +194,8 @@ class Ref:
         nn = self.L.ltref_init_object(_p(v), v.shape[0], _p(po), _p(ty), _p(pv), po.shape[0], _p(normals), _p(pn))
         return normals[:nn, :3].copy(), pn
 
+    def g_line(self, v1, v2, colour, r=0, g=0, b=0):
+        """the real G_line on projected {X, Y, Z} end points"""
+        a, bb = _i32(v1).copy(), _i32(v2).copy()
+        self.L.ltref_g_line(_p(a), _p(bb), int(colour), int(r), int(g), int(b))
+

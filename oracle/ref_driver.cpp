@@ -232,6 +232,12 @@ void ltref_scan_polygon(int *tuples,int length,int dim,int *miny,int *maxy,
  }
 }
 
+/* The real G_line (GraphicsBase.cpp:165-253); v1, v2 = projected {X, Y, Z} */
+void ltref_g_line(int *v1,int *v2,int colour,int r,int g,int b)
+{
+ G_line(v1,v2,colour,r,g,b);
+}
+
 /* The real M_init_polygon_object (EngPoly.cpp:355-459) without _PAINTER_: normals only.
  * types[np] = m_type.  normals[1024][4] receives the object's list (three words per
  * normal are defined), polynormals[*] (laid out like polyverts) the indices of polygons

@@ -15,7 +15,7 @@ EXPORTS = [
     "lt_texture_upload", "lt_transform", "lt_submit_object", "lt_submit_object_dev",
     "lt_submit_screen_polys", "lt_set_profiling", "lt_get_stage_ms", "lt_set_textured_order",
     "lt_bind_framebuffer", "lt_set_band", "lt_set_pipelining", "lt_shade_object_dev", "lt_shade_object",
-    "lt_plane_normals_dev", "lt_plane_normals",
+    "lt_plane_normals_dev", "lt_plane_normals", "lt_submit_lines_dev", "lt_submit_lines",
 ]
 
 
@@ -58,6 +58,8 @@ def lib():
     L.lt_shade_object.argtypes = L.lt_shade_object_dev.argtypes
     L.lt_plane_normals_dev.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
     L.lt_plane_normals.argtypes = L.lt_plane_normals_dev.argtypes
+    L.lt_submit_lines_dev.argtypes = [vp, vp, i32]
+    L.lt_submit_lines.argtypes = [vp, vp, i32]
     L.lt_set_pipelining.argtypes = [vp, i32]
     L.lt_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.lt_reset_counters.argtypes = [vp]

@@ -55,6 +55,7 @@ struct lt_ctx {
     hipStream_t gs = nullptr, rs = nullptr;            // streams in use: own_* or `stream`
     hipEvent_t ev_fork = nullptr;
     DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn;      // staging for host-pointer calls
+    DevBuf line_winner, line_colours, s_lines;   // wireframe: per-pixel winning line, per-polygon colour, staged lines
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
     int tex_log_h[LT_MAX_TEXTURES] = {};
@@ -347,6 +348,60 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     return LT_OK;
 }
 
+// G_clear with no fill kernel to do it: the rows of this context's band
+void fill_band(lt_ctx *c)
+{
+    if (!c->clear_pending) return;
+    const int y0 = c->band_y0 < 0 ? 0 : c->band_y0, y1 = c->band_y1 > c->H ? c->H : c->band_y1;
+    if (y0 < y1) launch_fill(c->rs, c->cbuf + (size_t)y0 * c->W, c->zbuf + (size_t)y0 * c->W, (size_t)(y1 - y0) * c->W, c->clear_colour);
+    c->clear_pending = false;
+}
+
+// Wireframe batches (M_WIRE objects, G_line lists) read the depth buffer and never write it, so
+// they run where the fills run, after them, and the next fill runs after them.
+int wire_begin(lt_ctx *c, hipStream_t *s)
+{
+    *s = c->rs;
+    if (c->pipelined && hipStreamQuery(c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));       // the inputs may come from the caller's stream
+        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_fork, 0));
+    }
+    fill_band(c);
+    const size_t bytes = (size_t)c->W * c->H * sizeof(unsigned);
+    if (bytes > c->line_winner.cap) {
+        int rc = ensure(c, c->line_winner, bytes);
+        if (rc) return rc;
+        HIPCHK(c, hipMemsetAsync(c->line_winner.p, 0, c->line_winner.cap, c->rs));     // the resolve kernel zeroes what it reads
+    }
+    return LT_OK;
+}
+
+int run_wire(lt_ctx *c, const int32_t *m, const int *d_verts, int nv, const int *d_polys, const int *d_aux, int np,
+             const int *d_pv, int npv, int log_focus, int max_edges)
+{
+    if (np > (1 << 27)) return fail(c, LT_ERR_ARG, "lt_submit_object: at most %d polygons in a wireframe batch", 1 << 27);
+    hipStream_t s;
+    int rc = wire_begin(c, &s);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->line_colours, (size_t)np * sizeof(int)))) return rc;
+    SetupArgs sa{};
+    sa.use_matrix = m ? 1 : 0;
+    if (m) for (int i = 0; i < 12; i++) sa.m[i] = m[i];
+    sa.verts = d_verts; sa.polys = d_polys; sa.polyaux = d_aux; sa.polyverts = d_pv;
+    sa.np = np; sa.nv = nv; sa.npv = npv;
+    sa.log_focus = log_focus;
+    sa.max_edges = (max_edges <= 0 || max_edges > 15) ? 15 : max_edges;
+    sa.W = c->W; sa.H = c->H;
+    sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
+    sa.status = c->status;
+    launch_wire(s, sa, c->zbuf, (unsigned *)c->line_winner.p, (int *)c->line_colours.p, c->cbuf);
+    HIPCHK(c, hipGetLastError());
+    c->frame_defined = true;
+    c->polys_in += (uint64_t)np;
+    return LT_OK;
+}
+
 int check_type(lt_ctx *c, int render_type, int *dim)
 {
     if (render_type == LT_FLAT) *dim = 3;
@@ -420,7 +475,8 @@ int lt_ctx_destroy(lt_ctx *c)
     if (c->gs) (void)hipStreamSynchronize(c->gs);
     if (c->rs) (void)hipStreamSynchronize(c->rs);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn};
+    DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn,
+                      &c->line_winner, &c->line_colours, &c->s_lines};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (lt_ctx::Work &w : c->work) {
@@ -518,11 +574,8 @@ int lt_clear(lt_ctx *c, int32_t lit_colour)
 
 static int materialize_clear(lt_ctx *c)
 {
-    if (c->clear_pending) {
-        launch_fill(c->rs, c->cbuf, c->zbuf, (size_t)c->W * c->H, c->clear_colour);
-        HIPCHK(c, hipGetLastError());
-        c->clear_pending = false;
-    }
+    fill_band(c);
+    HIPCHK(c, hipGetLastError());
     return LT_OK;
 }
 
@@ -781,7 +834,7 @@ int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts,
 {
     if (!c) return LT_ERR_ARG;
     int dim = 0, rc;
-    if ((rc = check_type(c, render_type, &dim))) return rc;
+    if (render_type != LT_WIRE && (rc = check_type(c, render_type, &dim))) return rc;
     if (np < 0 || nv < 0 || npv < 0) return fail(c, LT_ERR_ARG, "lt_submit_object: negative count");
     if (np == 0) return LT_OK;
     if (!d_verts || !d_polys || !d_polyverts) return fail(c, LT_ERR_ARG, "lt_submit_object: NULL array");
@@ -789,6 +842,7 @@ int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts,
     if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_submit_object: log_focus %d outside 0..30", log_focus);
     if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
     if ((rc = use_device(c))) return rc;
+    if (render_type == LT_WIRE) return run_wire(c, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts, npv, log_focus, max_edges);
     return run_batch(c, false, dim, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts, npv, render_type,
                      log_focus, force_linear, max_edges);
 }
@@ -814,9 +868,12 @@ int lt_submit_object(lt_ctx *c, const int32_t m[12], const int32_t *verts, int n
     HIPCHK(c, hipMemcpyAsync(c->s_pv.p, polyverts, (size_t)npv * 24, hipMemcpyHostToDevice, c->stream));
     if (polyaux) HIPCHK(c, hipMemcpyAsync(c->s_aux.p, polyaux, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return lt_submit_object_dev(c, m, (const int *)c->s_verts.p, nv, (const int *)c->s_polys.p,
-                                polyaux ? (const int *)c->s_aux.p : nullptr, np, (const int *)c->s_pv.p, npv,
-                                render_type, log_focus, force_linear, max_edges);
+    rc = lt_submit_object_dev(c, m, (const int *)c->s_verts.p, nv, (const int *)c->s_polys.p,
+                              polyaux ? (const int *)c->s_aux.p : nullptr, np, (const int *)c->s_pv.p, npv,
+                              render_type, log_focus, force_linear, max_edges);
+    // a wireframe batch reads the staging arrays on the stream of the fills
+    if (rc == LT_OK && render_type == LT_WIRE) HIPCHK(c, hipStreamSynchronize(c->rs));
+    return rc;
 }
 
 int lt_submit_screen_polys(lt_ctx *c, int kind, const int32_t *tuples, int ntuples, const int32_t *desc, int n,
@@ -837,6 +894,36 @@ int lt_submit_screen_polys(lt_ctx *c, int kind, const int32_t *tuples, int ntupl
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return run_batch(c, true, dim, nullptr, nullptr, 0, (const int *)c->s_polys.p, nullptr, n, (const int *)c->s_pv.p, ntuples,
                      kind, 0, 0, max_edges);
+}
+
+int lt_submit_lines_dev(lt_ctx *c, const int32_t *d_lines, int n)
+{
+    if (!c) return LT_ERR_ARG;
+    if (n == 0) return LT_OK;
+    if (n < 0 || !d_lines) return fail(c, LT_ERR_ARG, "lt_submit_lines: bad argument");
+    if (((size_t)d_lines & 15) != 0) return fail(c, LT_ERR_ARG, "lt_submit_lines: the array must be 16-byte aligned");
+    if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
+    int rc = use_device(c);
+    if (rc) return rc;
+    hipStream_t s;
+    if ((rc = wire_begin(c, &s))) return rc;
+    launch_lines(s, d_lines, n, c->W, c->H, c->band_y0, c->band_y1, c->zbuf, (unsigned *)c->line_winner.p, c->cbuf, c->status);
+    HIPCHK(c, hipGetLastError());
+    return LT_OK;
+}
+
+int lt_submit_lines(lt_ctx *c, const int32_t *lines, int n)
+{
+    if (!c) return LT_ERR_ARG;
+    if (n == 0) return LT_OK;
+    if (n < 0 || !lines) return fail(c, LT_ERR_ARG, "lt_submit_lines: bad argument");
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->rs));        // an earlier list may still be read
+    if ((rc = ensure(c, c->s_lines, (size_t)n * 32))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_lines.p, lines, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return lt_submit_lines_dev(c, (const int32_t *)c->s_lines.p, n);
 }
 
 }  // extern "C"

@@ -130,6 +130,9 @@ struct ShadeArgs {
     int lights[MAX_LIGHTS][8];       // {type, px,py,pz,pw, red,green,blue}
     Status *status;
 };
+void launch_wire(hipStream_t s, const SetupArgs &a, const int *zbuf, unsigned *winner, int *colours, int *cbuf);
+void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0, int by1, const int *zbuf, unsigned *winner,
+                  int *cbuf, Status *status);
 void launch_plane_normals(hipStream_t s, const int *verts, int nv, const int *polys, int np, const int *polyverts,
                           int npv, int *out, Status *status);
 void launch_shade(hipStream_t s, const ShadeArgs &a);

@@ -2088,8 +2088,249 @@ hipError_t launch_ordered(hipStream_t s, const RasterArgs &a)
     return hipSuccess;
 }
 
+// ------------------------------------------------------------------ wireframe
+
+// The two clips of G_line (GraphicsBase.cpp:191-193) are made with dimension 2: only X and Y
+// of an end point that a clipper moves are computed, and the depth read through the returned
+// pointer is the third word of one of the clipper's static stores (Clipp2D.cpp:99-104, 132,
+// 150).  A program that draws only wireframes never writes those words: 0, which is what a
+// moved end point gets here (after filled polygons the reference's value is a leftover of
+// the polygon clipper's last calls).
+template <int AX>
+__device__ __forceinline__ bool clip_line_xy(Tup<3> &v1, Tup<3> &v2, int bmax, bool &bad)
+{
+    Tup<2> p, q, o1, o2;
+    p.v[0] = v1.v[0]; p.v[1] = v1.v[1]; q.v[0] = v2.v[0]; q.v[1] = v2.v[1];
+    const bool swap = !(v1.v[AX] < v2.v[AX]);
+    const bool m1 = swap ? v1.v[AX] >= bmax : v1.v[AX] <= 0;
+    const bool m2 = swap ? v2.v[AX] <= 0 : v2.v[AX] >= bmax;
+    bool moved;
+    if (!clip_line<2, AX, true>(p, q, 0, bmax, o1, o2, moved, bad)) return false;
+    v1.v[0] = o1.v[0]; v1.v[1] = o1.v[1]; v1.v[2] = m1 ? 0 : v1.v[2];
+    v2.v[0] = o2.v[0]; v2.v[1] = o2.v[1]; v2.v[2] = m2 ? 0 : v2.v[2];
+    return true;
+}
+
+// G_line, GraphicsBase.cpp:165-253: the points of the line from v1 to v2 (both included),
+// each tested against the depth buffer, which a line does not write.  The reference's
+// later line overwrites an earlier one's pixel, so every pixel keeps the largest draw index
+// among the lines that pass there (`winner`, 0 = none); line_resolve_kernel turns indices
+// into colours.  Points outside rows [by0, by1) belong to another context's band.
+__device__ __forceinline__ void draw_line(int W, int H, int by0, int by1, const int *__restrict__ zbuf, unsigned *winner,
+                                          Tup<3> v1, Tup<3> v2, unsigned id, unsigned long long &tests, bool &bad)
+{
+    if (!clip_line_xy<0>(v1, v2, W - 1, bad)) return;
+    if (!clip_line_xy<1>(v1, v2, H - 1, bad)) return;
+    if (bad) return;
+    int dx = v2.v[0] - v1.v[0], dy = v2.v[1] - v1.v[1];
+    const int sx = dx < 0 ? -1 : 1, sy = dy < 0 ? -1 : 1;
+    dx = dx < 0 ? -dx : dx;
+    dy = dy < 0 ? -dy : dy;
+    const bool xmaj = dx > dy;
+    const int long_d = xmaj ? dx : dy, short_d = xmaj ? dy : dx;
+    int d = 2 * short_d - long_d;
+    const int add_dl = 2 * short_d, add_dh = 2 * (short_d - long_d);
+    int x = v1.v[0], y = v1.v[1], cur_z = v1.v[2];
+    const int inc_z = long_d != 0 ? tdiv_any(wsub(v2.v[2], cur_z), long_d) : 0;
+    for (int i = 0; i <= long_d; i++) {
+        if (y >= by0 && y < by1) {
+            const size_t pos = (size_t)y * W + x;
+            tests++;
+            if (cur_z < zbuf[pos]) atomicMax(winner + pos, id);
+        }
+        if (d >= 0) { d += add_dh; x += sx; y += sy; }
+        else { d += add_dl; x += xmaj ? sx : 0; y += xmaj ? 0 : sy; }
+        cur_z = wadd(cur_z, inc_z);
+    }
+}
+
+// M_render_polygon with M_WIRE (EngBase.cpp:393-431): tuples of X Y Z, volume test,
+// near-plane clip, perspective, back-face test on the first three projected tuples, then
+// G_line for every edge of the clipped polygon (the polygon itself is not clipped to the
+// screen; each line is).  One polygon per lane, the stages chained as in setup_one; line k
+// of polygon p has draw index 16 p + k + 1.
+__global__ void __launch_bounds__(128) wire_kernel(SetupArgs a, const int *__restrict__ zbuf, unsigned *winner,
+                                                   int *__restrict__ colours)
+{
+    const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false, drawn = false;
+    unsigned long long tests = 0;
+    if (poly < a.np) {
+        const int4 pd = ((const int4 *)a.polys)[poly];
+        const int colour = pd.x, e = pd.z, first = pd.w;
+        const int4 ax = a.polyaux ? ((const int4 *)a.polyaux)[poly] : make_int4(0, 0, 0, 0);
+        colours[poly] = cl_light(colour, ax.x, ax.y, ax.z);
+        bool go = true;
+        if (e < 2 || e + 1 > 16 || e > a.max_edges || first < 0 || (long long)first + e + 1 > (long long)a.npv) { bad = true; go = false; }
+        bool zclip = false;
+        if (go) {
+            int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+            for (int i = 0; i <= e; i++) {
+                const int idx = a.polyverts[(size_t)(first + i) * 6];
+                if ((unsigned)idx >= (unsigned)a.nv) { bad = true; go = false; break; }
+                const int4 p = load_vertex(a, idx);
+                mn[0] = min(mn[0], p.x); mx[0] = max(mx[0], p.x);
+                mn[1] = min(mn[1], p.y); mx[1] = max(mx[1], p.y);
+                mn[2] = min(mn[2], p.z); mx[2] = max(mx[2], p.z);
+            }
+            if (go) {           // C_volume_clipping, Clipp3D.cpp:46-58
+                if ((mx[2] < mn[0]) || (mx[2] < mn[1]) || (mx[2] < -mx[0]) || (mx[2] < -mx[1]) || (mx[2] <= 10)) go = false;
+                else zclip = mn[2] < 10;
+            }
+        }
+        if (go && zclip) {
+            // the clipped polygon must fit the reference's arrays (16 tuples): count first,
+            // because lines are drawn as the tuples appear
+            int zn = 0;
+            Tup<3> zprev;
+            for (int it = 0; it <= e; it++) {
+                const int4 p = load_vertex(a, a.polyverts[(size_t)(first + it) * 6]);
+                Tup<3> t, o1, o2;
+                t.v[0] = p.x; t.v[1] = p.y; t.v[2] = p.z;
+                bool moved;
+                if (it > 0 && clip_line<3, 2, false>(zprev, t, 10, 0, o1, o2, moved, bad)) zn += moved ? 2 : 1;
+                zprev = t;
+            }
+            if (zn + 1 > 16 || bad) { bad = true; go = false; }
+        }
+        if (go) {
+            const int xc = a.W / 2, yc = a.H / 2;
+            Tup<3> zprev, zfirst, q0, q1, qprev;
+            zprev = Tup<3>(); zfirst = zprev; q0 = zprev; q1 = zprev; qprev = zprev;
+            int zn = 0;
+            for (int it = 0; go && it <= e + 1; it++) {
+                Tup<3> zo0 = zprev, zo1 = zprev;
+                int cz = 0;
+                if (it <= e) {
+                    const int4 p = load_vertex(a, a.polyverts[(size_t)(first + it) * 6]);
+                    Tup<3> t;
+                    t.v[0] = p.x; t.v[1] = p.y; t.v[2] = p.z;
+                    if (!zclip) { zo0 = t; cz = 1; }
+                    else if (it > 0) {
+                        // C_polygon_z_clipping, Clipp3D.cpp:137-155
+                        Tup<3> o1, o2;
+                        bool moved;
+                        if (clip_line<3, 2, false>(zprev, t, 10, 0, o1, o2, moved, bad)) {
+                            zo0 = sel(moved, o1, o2);
+                            zo1 = o2;
+                            cz = moved ? 2 : 1;
+                        }
+                    }
+                    zprev = t;
+                } else if (zclip && zn > 0) {
+                    zo0 = zfirst; cz = 1;       // closing tuple = first tuple, Clipp3D.cpp:156
+                }
+                for (int k = 0; go && k < cz; k++) {
+                    const Tup<3> p = sel(k != 0, zo1, zo0);
+                    if (zn == 0) zfirst = p;
+                    // T_perspective, TransBs.cpp:425-432
+                    const int z = p.v[2];
+                    const double rz = drcp(z);
+                    Tup<3> q;
+                    q.v[0] = wadd(persp_div(p.v[0], a.log_focus, z, rz), xc);
+                    q.v[1] = wadd(persp_div(p.v[1], a.log_focus, z, rz), yc);
+                    q.v[2] = tdivr(-0x7ffff, rz);
+                    const unsigned id = (unsigned)poly * 16u + (unsigned)zn;        // index of line (zn-1, zn), plus one
+                    if (zn == 0) q0 = q;
+                    else if (zn == 1) q1 = q;
+                    else if (zn == 2) {
+                        // T_normal_z_negative, TransLn.cpp:218-223
+                        const long long c = (long long)wsub(q1.v[0], q0.v[0]) * (long long)wsub(q.v[1], q0.v[1]) -
+                                            (long long)wsub(q1.v[1], q0.v[1]) * (long long)wsub(q.v[0], q0.v[0]);
+                        if (!(c < 0)) go = false;
+                        else {
+                            drawn = true;
+                            draw_line(a.W, a.H, a.band_y0, a.band_y1, zbuf, winner, q0, q1, id - 1u, tests, bad);
+                            draw_line(a.W, a.H, a.band_y0, a.band_y1, zbuf, winner, q1, q, id, tests, bad);
+                        }
+                    } else {
+                        draw_line(a.W, a.H, a.band_y0, a.band_y1, zbuf, winner, qprev, q, id, tests, bad);
+                    }
+                    qprev = q;
+                    zn++;
+                }
+            }
+        }
+    }
+    Status *st = a.status + (blockIdx.x % STATUS_SLOTS);
+    if (tests) atomicAdd(&st->fragments, tests);
+    unsigned long long m = __ballot(drawn);
+    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->polys_drawn, (unsigned long long)__popcll(m));
+    m = __ballot(bad);
+    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->overflow_polys, (unsigned long long)__popcll(m));
+}
+
+// G_line for n lines in draw order: lines[i] = {x1, y1, z1, x2, y2, z2, lit colour, 0}
+__global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ lines, int n, int W, int H, int by0, int by1,
+                                                    const int *__restrict__ zbuf, unsigned *winner, Status *status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long tests = 0;
+    bool bad = false;
+    if (i < n) {
+        const int4 lo = ((const int4 *)lines)[2 * (size_t)i], hi = ((const int4 *)lines)[2 * (size_t)i + 1];
+        Tup<3> v1, v2;
+        v1.v[0] = lo.x; v1.v[1] = lo.y; v1.v[2] = lo.z;
+        v2.v[0] = lo.w; v2.v[1] = hi.x; v2.v[2] = hi.y;
+        draw_line(W, H, by0, by1, zbuf, winner, v1, v2, (unsigned)i + 1u, tests, bad);
+    }
+    Status *st = status + (blockIdx.x % STATUS_SLOTS);
+    if (tests) atomicAdd(&st->fragments, tests);
+    const unsigned long long m = __ballot(bad);
+    if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->overflow_polys, (unsigned long long)__popcll(m));
+}
+
+// colour of pixel p = colour of its winning line: col[((winner - 1) >> shift) * stride + offset]
+__global__ void __launch_bounds__(256) line_resolve_kernel(unsigned *winner, int *__restrict__ cbuf, size_t n,
+                                                           const int *__restrict__ col, int shift, int stride, int offset)
+{
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; p < n; p += step) {
+        const unsigned w = winner[p];
+        if (w) {
+            cbuf[p] = col[(size_t)((w - 1u) >> shift) * stride + offset];
+            winner[p] = 0u;
+        }
+    }
+}
+
+void launch_wire(hipStream_t s, const SetupArgs &a, const int *zbuf, unsigned *winner, int *colours, int *cbuf)
+{
+    if (a.np <= 0) return;
+    hipLaunchKernelGGL(wire_kernel, dim3((a.np + 127) / 128), dim3(128), 0, s, a, zbuf, winner, colours);
+    const size_t n = (size_t)a.W * a.H;
+    hipLaunchKernelGGL(line_resolve_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 8192)), dim3(256), 0, s, winner,
+                       cbuf, n, (const int *)colours, 4, 1, 0);
+}
+
+void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0, int by1, const int *zbuf, unsigned *winner,
+                  int *cbuf, Status *status)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(lines_kernel, dim3((n + 127) / 128), dim3(128), 0, s, lines, n, W, H, by0, by1, zbuf, winner, status);
+    const size_t np = (size_t)W * H;
+    hipLaunchKernelGGL(line_resolve_kernel, dim3((unsigned)std::min<size_t>((np + 255) / 256, 8192)), dim3(256), 0, s, winner,
+                       cbuf, np, lines, 0, 8, 6);
+}
+
+__global__ void __launch_bounds__(256) fill_scalar_kernel(int *c, int *z, size_t n, int colour)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { c[i] = colour; z[i] = INT_MAX; }
+}
+
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour)
 {
+    // 16-byte stores between a few leading and trailing words (a band may start at any row)
+    const size_t lead_c = ((16 - ((uintptr_t)cbuf & 15)) & 15) / 4, lead_z = ((16 - ((uintptr_t)zbuf & 15)) & 15) / 4;
+    if (lead_c != lead_z || n < 8) {
+        if (n) hipLaunchKernelGGL(fill_scalar_kernel, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, s, cbuf, zbuf, n, colour);
+        return;
+    }
+    if (lead_c) hipLaunchKernelGGL(fill_tail_kernel, dim3(1), dim3(4), 0, s, cbuf, zbuf, (size_t)0, lead_c, colour);
+    cbuf += lead_c; zbuf += lead_c; n -= lead_c;
     size_t n4 = n / 4;
     if (n4) {
         size_t blocks = (n4 + 255) / 256;

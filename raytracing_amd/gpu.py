@@ -162,6 +162,14 @@ class Context:
                                          _p(li), li.shape[0]))
         return pv, pa
 
+    def submit_lines(self, lines):
+        """G_line for int32[n][8] = {x1, y1, z1, x2, y2, z2, lit colour, 0}, in draw order"""
+        l = _i32(lines).reshape(-1, 8)
+        self._chk(self.L.lt_submit_lines(self.h_ctx, _p(l), l.shape[0]))
+
+    def submit_lines_dev(self, d_lines):
+        self._chk(self.L.lt_submit_lines_dev(self.h_ctx, _dp(d_lines), d_lines.shape[0]))
+
     def plane_normals_dev(self, d_verts, d_polys, d_polyverts, d_out):
         """T_normal_plane of every polygon's first three records (the first loop of
         M_init_polygon_object) on device arrays: d_out int32[np][4] = {nx, ny, nz, 0}."""

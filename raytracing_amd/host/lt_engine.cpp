@@ -34,12 +34,13 @@ int Ts[9], Tw[9], Tc[12];                            // self / world rotation, c
 int Cb[4] = {0, 0, 0, 0};                            // clip window
 
 // queued draws: consecutive calls of one kind form one batch
-enum QKind { Q_NONE, Q_SCREEN, Q_VIEW };
+enum QKind { Q_NONE, Q_SCREEN, Q_VIEW, Q_LINES };
 QKind q_kind = Q_NONE;
 int q_type = 0;                                      // LT_FLAT / LT_SHADED / LT_TEXTURED
 int q_focus = 0, q_force = 0;
 std::vector<int32_t> q_tuples, q_desc;               // Q_SCREEN
 std::vector<int32_t> q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
+std::vector<int32_t> q_lines;                        // Q_LINES: {x1 y1 z1 x2 y2 z2 lit-colour 0}
 int q_max_edges = 0;
 std::map<const void *, int> g_tex_handles;           // texel pointer -> handle
 int g_next_tex = 0;
@@ -83,8 +84,11 @@ void run_queue()
         chk(lt_submit_object(g_ctx, nullptr, q_verts.data(), (int)(q_verts.size() / 4), q_polys.data(), q_aux.data(),
                              (int)(q_polys.size() / 4), q_pv.data(), (int)(q_pv.size() / 6), q_type, q_focus, q_force,
                              q_max_edges));
+    } else if (q_kind == Q_LINES && !q_lines.empty()) {
+        chk(lt_submit_lines(g_ctx, q_lines.data(), (int)(q_lines.size() / 8)));
     }
     q_kind = Q_NONE;
+    q_lines.clear();
     q_tuples.clear(); q_desc.clear(); q_verts.clear(); q_polys.clear(); q_aux.clear(); q_pv.clear();
     q_max_edges = 0;
 }
@@ -198,6 +202,17 @@ static void queue_screen(int type, int dim, int *edges, int length, HW_pixel col
     if (length > q_max_edges) q_max_edges = length;
 }
 
+// GraphicsBase.cpp:165-253.  A clipped end point takes depth 0 (what the reference reads in
+// a program that draws only wireframes; see lt_submit_lines in lt_gpu.h).
+void G_line(int *vertex1, int *vertex2, HW_pixel colour, int red, int green, int blue)
+{
+    need_ctx();
+    open_queue(Q_LINES, 0);
+    const int32_t l[8] = {vertex1[0], vertex1[1], vertex1[2], vertex2[0], vertex2[1], vertex2[2],
+                          CL_light(colour, red, green, blue), 0};
+    q_lines.insert(q_lines.end(), l, l + 8);
+}
+
 void G_flat_polygon(int *edges, int length, HW_pixel colour, int red, int green, int blue)
 {
     queue_screen(LT_FLAT, G_LNG_FLAT, edges, length, CL_light(colour, red, green, blue), 0);
@@ -302,8 +317,9 @@ void M_set_camera(unsigned char alp, unsigned char bet, unsigned char gam, int x
 
 static int lt_type()
 {
-    if (g_rendering_type != M_FLAT && g_rendering_type != M_SHADED && g_rendering_type != M_TEXTURED)
-        HW_error((char *)"(Engine) only M_FLAT, M_SHADED and M_TEXTURED are drawn by the GPU path.\n");
+    if (g_rendering_type != M_WIRE && g_rendering_type != M_FLAT && g_rendering_type != M_SHADED &&
+        g_rendering_type != M_TEXTURED)
+        HW_error((char *)"(Engine) no such rendering type.\n");
     return g_rendering_type;
 }
 

@@ -45,6 +45,7 @@ extern int *G_z_buffer;
 extern long G_c_buffer_size;
 void G_init_graphics(void);
 void G_clear(HW_pixel colour, int red, int green, int blue);
+void G_line(int *vertex1, int *vertex2, HW_pixel colour, int red, int green, int blue);
 void G_flat_polygon(int *edges, int length, HW_pixel colour, int red, int green, int blue);
 void G_shaded_polygon(int *edges, int length, HW_pixel colour);
 void G_lin_textured_polygon(int *edges, int length, HW_pixel *texture, int log_texture_size);
@@ -64,6 +65,7 @@ void C_get_bounds(int *minx, int *miny, int *maxx, int *maxy);
 int C_set_bounds(int minx, int miny, int maxx, int maxy);
 
 // ---- Engine.h:80-90, 148-152, 209-238, 435-460
+#define M_WIRE 0x01
 #define M_FLAT 0x02
 #define M_SHADED 0x04
 #define M_TEXTURED 0x08

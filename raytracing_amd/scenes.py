@@ -18,7 +18,7 @@ from typing import List, Optional
 
 import numpy as np
 
-M_FLAT, M_SHADED, M_TEXTURED = 2, 4, 8          # reference Engine.h:81-83
+M_WIRE, M_FLAT, M_SHADED, M_TEXTURED = 1, 2, 4, 8   # reference Engine.h:80-83
 M_PLANNAR, M_QUAD_XY = 1, 4                     # reference Engine.h:190-193
 
 _MASK = (1 << 64) - 1

@@ -357,6 +357,69 @@ def normals_kats():
     return out
 
 
+WIRE_W, WIRE_H = 200, 150
+
+
+def wire_lines(seed, n, lo, hi, zlo, zhi, w=WIRE_W, h=WIRE_H):
+    """n lines {x1 y1 z1 x2 y2 z2 lit-colour 0}: end points uniform in [lo, hi] relative to the
+    screen (x in [lo, w + hi], y in [lo, h + hi]), depths in [zlo, zhi]"""
+    rng = S.Rng(seed)
+    l = np.zeros((n, 8), np.int32)
+    l[:, 0] = rng.ints(lo, w + hi, n); l[:, 1] = rng.ints(lo, h + hi, n)
+    l[:, 3] = rng.ints(lo, w + hi, n); l[:, 4] = rng.ints(lo, h + hi, n)
+    l[:, 2] = rng.ints(zlo, zhi, n); l[:, 5] = rng.ints(zlo, zhi, n)
+    l[:, 6] = rng.ints(1, 0xFFFFFF, n)
+    return l
+
+
+def wire_cases():
+    """name -> list of steps; a step is ("clear", colour) | ("object", scene, render_type, obj) |
+    ("lines", int32[n][8]).  Clipped lines appear only on frames without filled polygons
+    (their depth is then immaterial: nothing has written the depth buffer)."""
+    cases = {}
+    for k in range(3):
+        sc = S.gen_fuzz_polys(150, WIRE_W, WIRE_H, 7, 5000 + k, render_type=S.M_FLAT)
+        cases[f"wire_object_{k}"] = [("clear", 0x102030), ("object", sc, S.M_WIRE, (3 + k, 4, 5, 0, 0, 30))]
+    cases["lines_clipped"] = [("clear", 0), ("lines", wire_lines(77, 400, -150, 200, -1000, 1000))]
+    cases["lines_degenerate"] = [("clear", 0x000040), ("lines", np.array(
+        [[5, 5, 0, 5, 5, 0, 0x111111, 0], [0, 0, 1, WIRE_W - 1, WIRE_H - 1, 2, 0x222222, 0],
+         [WIRE_W - 1, 0, 3, 0, WIRE_H - 1, 3, 0x333333, 0], [-50, 70, 0, 400, 70, 0, 0x444444, 0],
+         [60, -90, 0, 60, 900, 0, 0x555555, 0], [0, 10, 0, 0, 140, 0, 0x666666, 0],
+         [WIRE_W - 1, 10, 0, WIRE_W - 1, 140, 0, 0x777777, 0], [-5, -5, 0, -1, -1, 0, 0x888888, 0],
+         [WIRE_W, 3, 0, WIRE_W + 40, 100, 0, 0x999999, 0], [10, 0, 0, 150, 0, 0, 0xaaaaaa, 0],
+         [10, WIRE_H - 1, 0, 150, WIRE_H - 1, 0, 0xbbbbbb, 0]], np.int32))]
+    sc = S.gen_c2(800, WIRE_W, WIRE_H, 7, radius=20, seed=5)
+    cases["mixed_unclipped"] = [("clear", 0), ("object", sc, S.M_SHADED, (0, 0, 0, 0, 0, 0)),
+                                ("lines", wire_lines(78, 300, 1, -2, -6200, -100)),
+                                ("object", S.gen_c2(300, WIRE_W, WIRE_H, 7, radius=25, seed=6), S.M_SHADED, (0, 0, 0, 0, 0, 0)),
+                                ("lines", wire_lines(79, 100, 1, -2, -6200, -100))]
+    return cases
+
+
+def run_wire_case(steps, be):
+    """be: oracle.port.Oracle or oracle.ref.Ref of WIRE_W x WIRE_H"""
+    for st in steps:
+        if st[0] == "clear":
+            be.clear(st[1], 255, 255, 255)
+        elif st[0] == "object":
+            _, sc, rt, obj = st
+            m = P.make_matrix((0, 0, 0, 0, 0, 0), obj, 0)
+            be.render_polys(P.transform(m, sc.verts), sc.polys, sc.polyaux, sc.polyverts, rt, sc.log_focus)
+        else:
+            for l in st[1]:
+                be.g_line(l[0:3], l[3:6], int(l[6]), 255, 255, 255)
+    return be.cbuf().copy(), be.zbuf().copy()
+
+
+def wire_kats():
+    """Wireframe frames (M_WIRE objects, G_line lists) drawn by the reference build: digests."""
+    out = {}
+    for name, steps in wire_cases().items():
+        c, z = run_wire_case(steps, R.Ref(WIRE_W, WIRE_H))
+        out[name] = dict(colour=S.frame_digest(c), depth=S.frame_digest(z), drawn=int((c != c[0, 0]).sum()))
+    return out
+
+
 def bench_frame():
     """The benchmark's own frame (1M Gouraud triangles at 1080p), drawn by the reference build."""
     sc = S.gen_c2(1_000_000, 1920, 1080, 10, radius=8)
@@ -372,6 +435,7 @@ def main():
     json.dump(bench_frame(), open(os.path.join(HERE, "bench_frame.json"), "w"), indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "shade_kats.npz"), **shade_kats())
     np.savez_compressed(os.path.join(HERE, "normals_kats.npz"), **normals_kats())
+    json.dump(wire_kats(), open(os.path.join(HERE, "wire_kats.json"), "w"), indent=1, sort_keys=True)
     if not os.path.isdir(REFDIR):
         raise SystemExit("needs /root/reference (run in the build container)")
     np.savez_compressed(os.path.join(HERE, "stage_kats.npz"), **stage_kats())
