@@ -131,6 +131,14 @@ int lt_bind_framebuffer(lt_ctx *ctx, int32_t *d_colour, int32_t *d_depth);
  * cleared, never drawn.  The fragment counters of the bands of one frame add up to the
  * whole frame's.  Default: the whole screen.  No counterpart in the reference. */
 int lt_set_band(lt_ctx *ctx, int y0, int y1);
+/* C_init_clipping (Clipp2D.cpp:36-42) / the result of C_set_bounds (:64-77): the 2-D clip
+ * window [minx, maxx] x [miny, maxy] of the batches submitted after this call -- the bounds
+ * of C_polygon_x_clipping, of the y clip inside GI_scan and of G_line's two clips.  Default:
+ * the whole screen, (0, 0, width-1, height-1) (Clipper.h:19-23).  The window must lie on the
+ * screen (the reference would write outside its buffers otherwise) and minx < maxx,
+ * miny < maxy (C_set_bounds reports other windows as "cannot clip" and its callers draw
+ * nothing).  lt_clear still clears the whole frame, as G_clear does. */
+int lt_set_clip_window(lt_ctx *ctx, int minx, int miny, int maxx, int maxy);
 int lt_get_counters(lt_ctx *ctx, lt_counters *out);   /* implies lt_flush */
 int lt_reset_counters(lt_ctx *ctx);
 

@@ -61,6 +61,7 @@ typedef struct lto_ctx {
     i32 *vs[6],*ve[6];           /* G_0..5_start / _end, GraphicsPoly.cpp:46-57 */
     int miny,maxy;
     int log_focus;               /* M_camera_log_focus */
+    i32 cx0,cy0,cx1,cy1;         /* C_x_clipping_min .. C_y_clipping_max, Clipp2D.cpp:23-26 */
     int fast_reset;              /* 1: reset only the rows a polygon touched */
     int touched_lo,touched_hi;
     const i32 *tex[LTO_MAX_TEXTURES];
@@ -106,6 +107,7 @@ lto_ctx *lto_create(int w,int h)
     for(j=0;j<6;j++){ c->vs[j]=(i32*)calloc(h,sizeof(i32)); c->ve[j]=(i32*)calloc(h,sizeof(i32)); }
     for(j=0;j<h;j++){ c->xs[j]=INT_MAX; c->xe[j]=INT_MIN; }
     c->touched_lo=0; c->touched_hi=-1;
+    c->cx0=0; c->cy0=0; c->cx1=w-1; c->cy1=h-1;       /* Clipper.h:19-23 */
     return c;
 }
 
@@ -121,6 +123,9 @@ void lto_destroy(lto_ctx *c)
 i32 *lto_cbuf(lto_ctx *c){ return c->cbuf; }
 i32 *lto_zbuf(lto_ctx *c){ return c->zbuf; }
 void lto_set_fast_reset(lto_ctx *c,int on){ c->fast_reset=on; }
+/* C_init_clipping, Clipp2D.cpp:36-42; the window must lie inside the screen */
+void lto_set_clip_window(lto_ctx *c,i32 minx,i32 miny,i32 maxx,i32 maxy)
+{ c->cx0=minx; c->cy0=miny; c->cx1=maxx; c->cy1=maxy; }
 void lto_set_texture(lto_ctx *c,int handle,const i32 *texels,int log_size)
 { c->tex[handle]=texels; c->tex_log[handle]=log_size; }
 
@@ -305,8 +310,8 @@ static int clip_line(const i32 *v1,const i32 *v2,int dim,int axis,i32 bmin,i32 b
 int lto_line_clipping(const lto_ctx *c,int axis,const i32 *v1,const i32 *v2,int dim,
                       i32 *o1,i32 *o2,int *first_moved)
 {
-    if(axis==0) return clip_line(v1,v2,dim,0,0,c->w-1,1,o1,o2,first_moved);
-    if(axis==1) return clip_line(v1,v2,dim,1,0,c->h-1,1,o1,o2,first_moved);
+    if(axis==0) return clip_line(v1,v2,dim,0,c->cx0,c->cx1,1,o1,o2,first_moved);
+    if(axis==1) return clip_line(v1,v2,dim,1,c->cy0,c->cy1,1,o1,o2,first_moved);
     return clip_line(v1,v2,dim,2,LTO_Z_MIN,0,0,o1,o2,first_moved);
 }
 
@@ -359,7 +364,7 @@ static void scan_edge(lto_ctx *c,const i32 *edge,int dim,int skip)
     int moved,i,j,nv=dim-2;
     i32 x,y,dx,dy,long_d,short_d,d,add_dh,add_dl,ixh,iyh,ixl,iyl;
 
-    if(!clip_line(edge,edge+skip,dim,1,0,c->h-1,1,a,b,&moved)) return;
+    if(!clip_line(edge,edge+skip,dim,1,c->cy0,c->cy1,1,a,b,&moved)) return;
 
     x=a[0]; y=a[1]; dx=b[0]; dy=b[1];
     if(y<c->miny) c->miny=y;
@@ -702,13 +707,13 @@ static void construct_tuples(const i32 *rec,i32 *to,const i32 *verts,int dim,int
  * that draws only wireframes those words are never written and stay 0 (static storage);
  * after filled polygons they hold leftovers of the polygon clipper's calls.  This
  * restatement, like the HIP path, uses 0. */
-static int clip_line_xy(i32 *v1,i32 *v2,int axis,i32 bmax)
+static int clip_line_xy(i32 *v1,i32 *v2,int axis,i32 bmin,i32 bmax)
 {
     i32 a[2]={v1[0],v1[1]},b[2]={v2[0],v2[1]},o1[2],o2[2];
     int moved,swap=!(v1[axis]<v2[axis]);
-    int m1=swap?(v1[axis]>=bmax):(v1[axis]<=0);
-    int m2=swap?(v2[axis]<=0):(v2[axis]>=bmax);
-    if(!clip_line(a,b,2,axis,0,bmax,1,o1,o2,&moved)) return 0;
+    int m1=swap?(v1[axis]>=bmax):(v1[axis]<=bmin);
+    int m2=swap?(v2[axis]<=bmin):(v2[axis]>=bmax);
+    if(!clip_line(a,b,2,axis,bmin,bmax,1,o1,o2,&moved)) return 0;
     v1[0]=o1[0]; v1[1]=o1[1]; if(m1) v1[2]=0;
     v2[0]=o2[0]; v2[1]=o2[1]; if(m2) v2[2]=0;
     return 1;
@@ -721,8 +726,8 @@ void lto_g_line(lto_ctx *c,const i32 *vertex1,const i32 *vertex2,i32 colour,i32 
     i32 hw=lto_cl_light(colour,r,g,b);
     i32 dx,dy,long_d,short_d,d,add_dh,add_dl,cur_z,inc_z=0;
     int inc_xh,inc_yh,inc_xl,inc_yl,x,y,i;
-    if(!clip_line_xy(v1,v2,0,c->w-1)) return;
-    if(!clip_line_xy(v1,v2,1,c->h-1)) return;
+    if(!clip_line_xy(v1,v2,0,c->cx0,c->cx1)) return;
+    if(!clip_line_xy(v1,v2,1,c->cy0,c->cy1)) return;
     dx=v2[0]-v1[0]; dy=v2[1]-v1[1];
     if(dx<0){ dx=-dx; inc_xh=-1; inc_xl=-1; } else { inc_xh=1; inc_xl=1; }
     if(dy<0){ dy=-dy; inc_yh=-1; inc_yl=-1; } else { inc_yh=1; inc_yl=1; }

@@ -65,6 +65,8 @@ def lib():
         L.lto_shade_polys.restype = C.c_int
         L.lto_shade_polys.argtypes = ([C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p, C.c_int] * 2 + [C.c_void_p, C.c_int]
                                       + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
+        L.lto_set_clip_window.restype = None
+        L.lto_set_clip_window.argtypes = [C.c_void_p] + [C.c_int32] * 4
         L.lto_g_line.restype = None
         L.lto_g_line.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4
         L.lto_normal_plane.restype = C.c_int
@@ -173,6 +175,10 @@ class Oracle:
         t = _i32(tuples).reshape(-1, 8)
         O, u, v = _i32(O), _i32(u), _i32(v)
         self.L.lto_g_prp_polygon(self.c, _p(t), t.shape[0] - 1, _p(O), _p(u), _p(v), tex, log_scale, log_focus)
+
+    def set_clip_window(self, minx, miny, maxx, maxy):
+        """C_init_clipping"""
+        self.L.lto_set_clip_window(self.c, int(minx), int(miny), int(maxx), int(maxy))
 
     def g_line(self, v1, v2, colour, r=0, g=0, b=0):
         """G_line on projected {X, Y, Z} end points"""

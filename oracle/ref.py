@@ -199,3 +199,7 @@ class Ref:
         a, bb = _i32(v1).copy(), _i32(v2).copy()
         self.L.ltref_g_line(_p(a), _p(bb), int(colour), int(r), int(g), int(b))
 
+    def set_clip_window(self, minx, miny, maxx, maxy):
+        """C_init_clipping; stays in force for this library (a process-wide global of the reference)"""
+        self.L.ltref_init_clipping(int(minx), int(miny), int(maxx), int(maxy))
+

@@ -232,6 +232,12 @@ void ltref_scan_polygon(int *tuples,int length,int dim,int *miny,int *maxy,
  }
 }
 
+/* C_init_clipping (Clipp2D.cpp:36-42): the 2-D clip window of everything drawn next */
+void ltref_init_clipping(int minx,int miny,int maxx,int maxy)
+{
+ C_init_clipping(minx,miny,maxx,maxy);
+}
+
 /* The real G_line (GraphicsBase.cpp:165-253); v1, v2 = projected {X, Y, Z} */
 void ltref_g_line(int *v1,int *v2,int colour,int r,int g,int b)
 {

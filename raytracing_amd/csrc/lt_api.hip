@@ -32,6 +32,7 @@ struct lt_ctx {
     int *cbuf = nullptr, *zbuf = nullptr;          // the frame being drawn (own or bound)
     int *own_cbuf = nullptr, *own_zbuf = nullptr;  // allocated by lt_ctx_create
     int band_y0 = 0, band_y1 = 0;                  // rows this context draws
+    ClipWindow clip{0, 0, 0, 0};                   // C_x_clipping_min .. C_y_clipping_max for the batches submitted next
     bool clear_pending = false;
     int clear_colour = 0;
     bool frame_defined = false;
@@ -231,7 +232,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         if (w.in_use) HIPCHK(c, hipStreamWaitEvent(gs, w.raster_done, 0));
     }
     if ((rc = ensure(c, w.hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
-    // the fill fetches edges 0..2 of every listed polygon without waiting for its header: at least three planes
+    // one record (header copy + edges 0..2) per slot, then the planes of edges 3 and up
     if ((rc = ensure(c, w.edges, (size_t)np * (16 + (emax < 3 ? 3 : emax) * edge_ints(na) * sizeof(int))))) return rc;
     if ((rc = ensure(c, w.list, (size_t)capacity * sizeof(unsigned)))) return rc;
     const bool want_prp = !screen && dim == 8;
@@ -276,6 +277,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.sq_desc = (int *)w.sq_desc.p; sa.sq_tuples = (int *)w.sq_tuples.p; sa.sq_queue = (uint2 *)w.sq_queue.p;
     sa.sq_count = sa.queue_count + QUEUES * QUEUE_COUNT_STRIDE;
     sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
+    sa.cx0 = c->clip.x0; sa.cy0 = c->clip.y0; sa.cx1 = c->clip.x1; sa.cy1 = c->clip.y1;
     // Screens with more tiles than the LDS histogram of the count kernel holds: set-up adds the
     // references itself (with few tiles the adds pile up on the same words and stall set-up).
     const bool fused = c->ntiles > BIN_MAX_TILES;
@@ -394,6 +396,7 @@ int run_wire(lt_ctx *c, const int32_t *m, const int *d_verts, int nv, const int 
     sa.max_edges = (max_edges <= 0 || max_edges > 15) ? 15 : max_edges;
     sa.W = c->W; sa.H = c->H;
     sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
+    sa.cx0 = c->clip.x0; sa.cy0 = c->clip.y0; sa.cx1 = c->clip.x1; sa.cy1 = c->clip.y1;
     sa.status = c->status;
     launch_wire(s, sa, c->zbuf, (unsigned *)c->line_winner.p, (int *)c->line_colours.p, c->cbuf);
     HIPCHK(c, hipGetLastError());
@@ -430,6 +433,7 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     c->device = device;
     c->W = width; c->H = height;
     c->band_y0 = 0; c->band_y1 = height;
+    c->clip = ClipWindow{0, 0, width - 1, height - 1};     // C_init_clipping defaults, Clipper.h:19-23
     c->tiles_x = (width + TW - 1) / TW; c->tiles_y = (height + TH - 1) / TH;
     c->ntiles = c->tiles_x * c->tiles_y;
     size_t n = (size_t)width * height;
@@ -547,6 +551,16 @@ int lt_set_band(lt_ctx *c, int y0, int y1)
     if (!c) return LT_ERR_ARG;
     if (y0 < 0 || y1 > c->H || y0 >= y1) return fail(c, LT_ERR_ARG, "lt_set_band: rows [%d, %d) outside [0, %d)", y0, y1, c->H);
     c->band_y0 = y0; c->band_y1 = y1;
+    return LT_OK;
+}
+
+int lt_set_clip_window(lt_ctx *c, int minx, int miny, int maxx, int maxy)
+{
+    if (!c) return LT_ERR_ARG;
+    if (minx < 0 || miny < 0 || maxx > c->W - 1 || maxy > c->H - 1 || minx >= maxx || miny >= maxy)
+        return fail(c, LT_ERR_ARG, "lt_set_clip_window: (%d, %d)-(%d, %d) is empty or leaves the %d x %d screen", minx, miny, maxx,
+                    maxy, c->W, c->H);
+    c->clip = ClipWindow{minx, miny, maxx, maxy};
     return LT_OK;
 }
 
@@ -907,7 +921,7 @@ int lt_submit_lines_dev(lt_ctx *c, const int32_t *d_lines, int n)
     if (rc) return rc;
     hipStream_t s;
     if ((rc = wire_begin(c, &s))) return rc;
-    launch_lines(s, d_lines, n, c->W, c->H, c->band_y0, c->band_y1, c->zbuf, (unsigned *)c->line_winner.p, c->cbuf, c->status);
+    launch_lines(s, d_lines, n, c->W, c->H, c->band_y0, c->band_y1, c->clip, c->zbuf, (unsigned *)c->line_winner.p, c->cbuf, c->status);
     HIPCHK(c, hipGetLastError());
     return LT_OK;
 }

@@ -89,6 +89,7 @@ struct SetupArgs {
     int detect_order;
     int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
     int band_y0, band_y1;    // rows [band_y0, band_y1) are drawn by this context (whole screen: 0, H)
+    int cx0, cy0, cx1, cy1;  // 2-D clip window C_x_clipping_min .. C_y_clipping_max (whole screen: 0, 0, W-1, H-1)
     unsigned *tile_count;    // non-null: set-up counts the tile references itself (no count kernel)
     Status *status;
 };
@@ -131,8 +132,9 @@ struct ShadeArgs {
     Status *status;
 };
 void launch_wire(hipStream_t s, const SetupArgs &a, const int *zbuf, unsigned *winner, int *colours, int *cbuf);
-void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0, int by1, const int *zbuf, unsigned *winner,
-                  int *cbuf, Status *status);
+struct ClipWindow { int x0, y0, x1, y1; };
+void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0, int by1, ClipWindow cw, const int *zbuf,
+                  unsigned *winner, int *cbuf, Status *status);
 void launch_plane_normals(hipStream_t s, const int *verts, int nv, const int *polys, int np, const int *polyverts,
                           int npv, int *out, Status *status);
 void launch_shade(hipStream_t s, const ShadeArgs &a);

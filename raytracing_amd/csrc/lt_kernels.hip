@@ -497,7 +497,7 @@ __device__ __forceinline__ const int4 *edge_piece(const int *edges, int np, int 
 
 // Edge record of one scanned edge v1 -> v2 (after the y clip): GI_scan's set-up,
 // GraphicsPoly.cpp:147-176.  record = {x1|y1<<16, x2|y2<<16, Zstart, Zinc, other starts..,
-// other incs..} in 16-byte pieces; edge `slot` of every polygon lies in plane `slot`.
+// other incs..} in 16-byte pieces, placed by edge_piece().
 template <int DIM>
 __device__ __forceinline__ void make_edge_record(const Tup<DIM> &v1, const Tup<DIM> &v2, int (&rec)[edge_ints(DIM - 2)])
 {
@@ -677,11 +677,11 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
                 t[i].v[0] = wadd(persp_div(t[i].v[0], a.log_focus, z, rz), xc);
                 t[i].v[1] = wadd(persp_div(t[i].v[1], a.log_focus, z, rz), yc);
                 t[i].v[2] = tdivr(-0x7ffff, rz);
-                inside = inside && t[i].v[0] > 0 && t[i].v[0] < a.W - 1 && t[i].v[1] > 0 && t[i].v[1] < a.H - 1;
-                left = left && t[i].v[0] <= 0;
-                right = right && t[i].v[0] >= a.W - 1;
-                above = above && t[i].v[1] <= 0;
-                below = below && t[i].v[1] >= a.H - 1;
+                inside = inside && t[i].v[0] > a.cx0 && t[i].v[0] < a.cx1 && t[i].v[1] > a.cy0 && t[i].v[1] < a.cy1;
+                left = left && t[i].v[0] <= a.cx0;
+                right = right && t[i].v[0] >= a.cx1;
+                above = above && t[i].v[1] <= a.cy0;
+                below = below && t[i].v[1] >= a.cy1;
             }
             // Wholly on the outer side of one screen border: the x clipper drops every
             // edge whose two ends are at or beyond the same bound (Clipp2D.cpp:115-118),
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
 //   X stage  C_polygon_x_clipping  edges of the projected polygon -> x-clipped tuples
 //   S stage  GI_scan front end     y clip of each edge, increments -> edge records
 //
-// Edge records go to the planes of the polygon's output slot (`slot`: given by the fast
+// Edge records go to the record and planes of the polygon's output slot (`slot`: given by the fast
 // kernel for queued polygons, the polygon's own index otherwise) while the stream runs
 // and are made visible by the header written at the end (n_edges == 0: nothing to draw).
 //
@@ -950,7 +950,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
     int first_view_z = 0;             // clipped[2] of EngBase.cpp:492
     Tup<DIM> org0 = zprev, org1 = zprev, org2 = zprev;   // original1[0..2] of EngBase.cpp:495-498 (textured only)
     Tup<DIM> zfirst_view = zprev;                         // `clipped` tuple 0, view space
-    const int wx = a.W - 1, hy = a.H - 1, xc = a.W / 2, yc = a.H / 2;
+    const int xc = a.W / 2, yc = a.H / 2;
 
     // object mode: iterations 0..e read the tuples, iteration e+1 is the closing event
     // of a z-clipped polygon.  screen mode: iterations 0..e read the tuples.
@@ -1042,7 +1042,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
             if (xn > 0) {
                 Tup<DIM> o1, o2;
                 bool moved;
-                if (clip_line<DIM, 0, true>(xprev, p, 0, wx, o1, o2, moved, bad)) {
+                if (clip_line<DIM, 0, true>(xprev, p, a.cx0, a.cx1, o1, o2, moved, bad)) {
                     xo0 = sel(moved, o1, o2);
                     xo1 = o2;
                     cx = moved ? 2 : 1;
@@ -1064,7 +1064,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
                     // GI_scan, GraphicsPoly.cpp:134-176
                     Tup<DIM> v1, v2;
                     bool moved;
-                    if (clip_line<DIM, 1, true>(sprev, s, 0, hy, v1, v2, moved, bad)) {
+                    if (clip_line<DIM, 1, true>(sprev, s, a.cy0, a.cy1, v1, v2, moved, bad)) {
                         miny = min(miny, min(v1.v[1], v2.v[1]));
                         maxy = max(maxy, max(v1.v[1], v2.v[1]));
                         if (ne < a.emax) store_edge_record<DIM>(a, slot, ne, v1, v2);
@@ -1748,7 +1748,7 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     // ---- depth pass.  Loads are software-pipelined: while a round's rows are drawn, the
     // header and the depth pieces of the three first edge records of the next round's
     // polygons are in flight, and so is the list entry of the round after that.  The edge
-    // pieces do not wait for the header: planes 0..2 of the pool exist for every polygon.
+    // pieces do not wait for the header: the record of every slot exists, whatever its edge count.
     const unsigned rounds = (lcnt + RASTER_THREADS - 1) / RASTER_THREADS;
     const int4 zero4 = make_int4(0, 0, 0, 0);
     // list entries are dealt to the waves in turn (entry e of a round goes to wave e % 4),
@@ -2097,15 +2097,15 @@ hipError_t launch_ordered(hipStream_t s, const RasterArgs &a)
 // moved end point gets here (after filled polygons the reference's value is a leftover of
 // the polygon clipper's last calls).
 template <int AX>
-__device__ __forceinline__ bool clip_line_xy(Tup<3> &v1, Tup<3> &v2, int bmax, bool &bad)
+__device__ __forceinline__ bool clip_line_xy(Tup<3> &v1, Tup<3> &v2, int bmin, int bmax, bool &bad)
 {
     Tup<2> p, q, o1, o2;
     p.v[0] = v1.v[0]; p.v[1] = v1.v[1]; q.v[0] = v2.v[0]; q.v[1] = v2.v[1];
     const bool swap = !(v1.v[AX] < v2.v[AX]);
-    const bool m1 = swap ? v1.v[AX] >= bmax : v1.v[AX] <= 0;
-    const bool m2 = swap ? v2.v[AX] <= 0 : v2.v[AX] >= bmax;
+    const bool m1 = swap ? v1.v[AX] >= bmax : v1.v[AX] <= bmin;
+    const bool m2 = swap ? v2.v[AX] <= bmin : v2.v[AX] >= bmax;
     bool moved;
-    if (!clip_line<2, AX, true>(p, q, 0, bmax, o1, o2, moved, bad)) return false;
+    if (!clip_line<2, AX, true>(p, q, bmin, bmax, o1, o2, moved, bad)) return false;
     v1.v[0] = o1.v[0]; v1.v[1] = o1.v[1]; v1.v[2] = m1 ? 0 : v1.v[2];
     v2.v[0] = o2.v[0]; v2.v[1] = o2.v[1]; v2.v[2] = m2 ? 0 : v2.v[2];
     return true;
@@ -2116,11 +2116,12 @@ __device__ __forceinline__ bool clip_line_xy(Tup<3> &v1, Tup<3> &v2, int bmax, b
 // later line overwrites an earlier one's pixel, so every pixel keeps the largest draw index
 // among the lines that pass there (`winner`, 0 = none); line_resolve_kernel turns indices
 // into colours.  Points outside rows [by0, by1) belong to another context's band.
-__device__ __forceinline__ void draw_line(int W, int H, int by0, int by1, const int *__restrict__ zbuf, unsigned *winner,
-                                          Tup<3> v1, Tup<3> v2, unsigned id, unsigned long long &tests, bool &bad)
+__device__ __forceinline__ void draw_line(int W, const ClipWindow cw, int by0, int by1, const int *__restrict__ zbuf,
+                                          unsigned *winner, Tup<3> v1, Tup<3> v2, unsigned id, unsigned long long &tests,
+                                          bool &bad)
 {
-    if (!clip_line_xy<0>(v1, v2, W - 1, bad)) return;
-    if (!clip_line_xy<1>(v1, v2, H - 1, bad)) return;
+    if (!clip_line_xy<0>(v1, v2, cw.x0, cw.x1, bad)) return;
+    if (!clip_line_xy<1>(v1, v2, cw.y0, cw.y1, bad)) return;
     if (bad) return;
     int dx = v2.v[0] - v1.v[0], dy = v2.v[1] - v1.v[1];
     const int sx = dx < 0 ? -1 : 1, sy = dy < 0 ? -1 : 1;
@@ -2153,6 +2154,7 @@ __global__ void __launch_bounds__(128) wire_kernel(SetupArgs a, const int *__res
                                                    int *__restrict__ colours)
 {
     const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    const ClipWindow cw = {a.cx0, a.cy0, a.cx1, a.cy1};
     bool bad = false, drawn = false;
     unsigned long long tests = 0;
     if (poly < a.np) {
@@ -2240,11 +2242,11 @@ __global__ void __launch_bounds__(128) wire_kernel(SetupArgs a, const int *__res
                         if (!(c < 0)) go = false;
                         else {
                             drawn = true;
-                            draw_line(a.W, a.H, a.band_y0, a.band_y1, zbuf, winner, q0, q1, id - 1u, tests, bad);
-                            draw_line(a.W, a.H, a.band_y0, a.band_y1, zbuf, winner, q1, q, id, tests, bad);
+                            draw_line(a.W, cw, a.band_y0, a.band_y1, zbuf, winner, q0, q1, id - 1u, tests, bad);
+                            draw_line(a.W, cw, a.band_y0, a.band_y1, zbuf, winner, q1, q, id, tests, bad);
                         }
                     } else {
-                        draw_line(a.W, a.H, a.band_y0, a.band_y1, zbuf, winner, qprev, q, id, tests, bad);
+                        draw_line(a.W, cw, a.band_y0, a.band_y1, zbuf, winner, qprev, q, id, tests, bad);
                     }
                     qprev = q;
                     zn++;
@@ -2261,7 +2263,7 @@ __global__ void __launch_bounds__(128) wire_kernel(SetupArgs a, const int *__res
 }
 
 // G_line for n lines in draw order: lines[i] = {x1, y1, z1, x2, y2, z2, lit colour, 0}
-__global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ lines, int n, int W, int H, int by0, int by1,
+__global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ lines, int n, int W, ClipWindow cw, int by0, int by1,
                                                     const int *__restrict__ zbuf, unsigned *winner, Status *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2272,7 +2274,7 @@ __global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ line
         Tup<3> v1, v2;
         v1.v[0] = lo.x; v1.v[1] = lo.y; v1.v[2] = lo.z;
         v2.v[0] = lo.w; v2.v[1] = hi.x; v2.v[2] = hi.y;
-        draw_line(W, H, by0, by1, zbuf, winner, v1, v2, (unsigned)i + 1u, tests, bad);
+        draw_line(W, cw, by0, by1, zbuf, winner, v1, v2, (unsigned)i + 1u, tests, bad);
     }
     Status *st = status + (blockIdx.x % STATUS_SLOTS);
     if (tests) atomicAdd(&st->fragments, tests);
@@ -2304,11 +2306,11 @@ void launch_wire(hipStream_t s, const SetupArgs &a, const int *zbuf, unsigned *w
                        cbuf, n, (const int *)colours, 4, 1, 0);
 }
 
-void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0, int by1, const int *zbuf, unsigned *winner,
-                  int *cbuf, Status *status)
+void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0, int by1, ClipWindow cw, const int *zbuf,
+                  unsigned *winner, int *cbuf, Status *status)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(lines_kernel, dim3((n + 127) / 128), dim3(128), 0, s, lines, n, W, H, by0, by1, zbuf, winner, status);
+    hipLaunchKernelGGL(lines_kernel, dim3((n + 127) / 128), dim3(128), 0, s, lines, n, W, cw, by0, by1, zbuf, winner, status);
     const size_t np = (size_t)W * H;
     hipLaunchKernelGGL(line_resolve_kernel, dim3((unsigned)std::min<size_t>((np + 255) / 256, 8192)), dim3(256), 0, s, winner,
                        cbuf, np, lines, 0, 8, 6);

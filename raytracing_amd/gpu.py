@@ -162,6 +162,10 @@ class Context:
                                          _p(li), li.shape[0]))
         return pv, pa
 
+    def set_clip_window(self, minx, miny, maxx, maxy):
+        """C_init_clipping for the batches submitted next"""
+        self._chk(self.L.lt_set_clip_window(self.h_ctx, int(minx), int(miny), int(maxx), int(maxy)))
+
     def submit_lines(self, lines):
         """G_line for int32[n][8] = {x1, y1, z1, x2, y2, z2, lit colour, 0}, in draw order"""
         l = _i32(lines).reshape(-1, 8)

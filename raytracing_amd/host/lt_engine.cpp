@@ -285,11 +285,22 @@ void T_cancatinated_rotation(int *from, int *to, int length)
 
 // ------------------------------------------------------------------ clip window (Clipp2D.cpp:35-82)
 
+// Clipp2D.cpp:36-77.  Draws queued so far keep the window they were issued under.  A window
+// that is empty or leaves the screen cannot be handed to the GPU: C_set_bounds then reports
+// "no clipping window" (its callers skip the drawing), C_init_clipping stops.
+static void apply_window()
+{
+    if (!g_ctx) return;
+    run_queue();
+    chk(lt_set_clip_window(g_ctx, Cb[0], Cb[1], Cb[2], Cb[3]));
+}
+
 void C_init_clipping(int minx, int miny, int maxx, int maxy)
 {
-    if (g_ctx && (minx != 0 || miny != 0 || maxx != g_w - 1 || maxy != g_h - 1))
-        HW_error((char *)"(Clipper) only the full-screen clip window is supported by the GPU path.\n");
+    if (g_ctx && (minx < 0 || miny < 0 || maxx > g_w - 1 || maxy > g_h - 1 || minx >= maxx || miny >= maxy))
+        HW_error((char *)"(Clipper) the clip window must be a non-empty part of the screen.\n");
     Cb[0] = minx; Cb[1] = miny; Cb[2] = maxx; Cb[3] = maxy;
+    apply_window();
 }
 
 void C_get_bounds(int *minx, int *miny, int *maxx, int *maxy)
@@ -299,8 +310,12 @@ void C_get_bounds(int *minx, int *miny, int *maxx, int *maxy)
 
 int C_set_bounds(int minx, int miny, int maxx, int maxy)
 {
-    if (minx > Cb[0] || miny > Cb[1] || maxx < Cb[2] || maxy < Cb[3])
-        HW_error((char *)"(Clipper) clip windows smaller than the screen are not supported by the GPU path.\n");
+    if (minx > Cb[0]) Cb[0] = minx;
+    if (maxx < Cb[2]) Cb[2] = maxx;
+    if (miny > Cb[1]) Cb[1] = miny;
+    if (maxy < Cb[3]) Cb[3] = maxy;
+    if (Cb[0] >= Cb[2] || Cb[1] >= Cb[3]) return 0;       // no window: the caller draws nothing (EngBase.cpp:629)
+    apply_window();
     return 1;
 }
 

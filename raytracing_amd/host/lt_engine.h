@@ -12,8 +12,8 @@
 //    observed -- HW_flush() (the place of the reference's HW_blit, LightTrack.cpp:284-298)
 //    -- or when G_clear is called.  After HW_flush, G_c_buffer and G_z_buffer hold the
 //    frame in host memory exactly as the reference leaves them;
-//  * the clip window is the full screen (C_init_clipping defaults, Clipper.h:19-23);
-//    C_set_bounds to a smaller window is refused through HW_error.
+//  * the clip window (C_init_clipping, C_set_bounds) must be a non-empty part of the screen:
+//    the reference would write outside its buffers with any other window.
 #pragma once
 #include <stdint.h>
 

@@ -21,6 +21,8 @@ int *lte_zbuf(void) { return G_z_buffer; }
 void lte_clear(int colour, int r, int g, int b) { G_clear(colour, r, g, b); }
 void lte_flush(void) { HW_flush(); }
 int lte_cl_light(int c, int r, int g, int b) { return CL_light(c, r, g, b); }
+void lte_init_clipping(int minx, int miny, int maxx, int maxy) { C_init_clipping(minx, miny, maxx, maxy); }
+int lte_set_bounds(int minx, int miny, int maxx, int maxy) { return C_set_bounds(minx, miny, maxx, maxy); }
 void lte_g_line(int *v1, int *v2, int colour, int r, int g, int b) { G_line(v1, v2, colour, r, g, b); }
 
 static void fill(M_polygon *p, M_texture *texs, const int *polys, const int *aux, int *pv, int i)

@@ -396,11 +396,44 @@ def wire_cases():
     return cases
 
 
+def window_cases():
+    """Frames drawn under clip windows smaller than the screen (C_init_clipping): steps as in
+    wire_cases plus ("window", (minx, miny, maxx, maxy)) and ("gpolys", kind, polygons of
+    gen_screen_polys).  Lines that a window clips come before any filled polygon."""
+    w, h = WIRE_W, WIRE_H
+    cases = {}
+    for k, rt in enumerate((S.M_FLAT, S.M_SHADED, S.M_TEXTURED)):
+        sc = S.gen_fuzz_polys(160, w, h, 7, 6000 + k, render_type=rt, textured=rt == S.M_TEXTURED, equal_lights=True)
+        cases[f"object_{rt}"] = [("clear", 0x101010), ("window", (30 + k, 20, 170, 120 - k)), ("object", sc, rt, (2, 3, 4, 0, 0, 20))]
+    cases["screen_polys"] = [("clear", 0), ("window", (50, 40, 150, 110)), ("gpolys", 4, S.gen_screen_polys(80, w, h, seed=61, dim=6))]
+    a = S.gen_c2(700, w, h, 7, radius=25, seed=62)
+    b = S.gen_c2(700, w, h, 7, radius=25, seed=63)
+    cases["two_windows"] = [("clear", 0x000030), ("window", (0, 0, 99, h - 1)), ("lines", wire_lines(64, 150, -80, 80, -500, 500)),
+                            ("object", a, S.M_SHADED, (0, 0, 0, 0, 0, 0)),
+                            ("window", (100, 10, w - 1, 100)), ("object", b, S.M_SHADED, (0, 0, 0, 0, 0, 0)),
+                            ("window", (0, 0, w - 1, h - 1)), ("lines", wire_lines(65, 80, 1, -2, -6200, -100))]
+    sc = S.gen_fuzz_polys(150, w, h, 7, 6007, render_type=S.M_FLAT)
+    cases["wire_object"] = [("clear", 0), ("window", (25, 25, 120, 140)), ("object", sc, S.M_WIRE, (3, 4, 5, 0, 0, 30))]
+    return cases
+
+
 def run_wire_case(steps, be):
     """be: oracle.port.Oracle or oracle.ref.Ref of WIRE_W x WIRE_H"""
+    try:
+        return _run_steps(steps, be)
+    finally:
+        be.set_clip_window(0, 0, be.w - 1, be.h - 1)        # a process-wide global in the reference build
+
+
+def _run_steps(steps, be):
     for st in steps:
         if st[0] == "clear":
             be.clear(st[1], 255, 255, 255)
+        elif st[0] == "window":
+            be.set_clip_window(*st[1])
+        elif st[0] == "gpolys":
+            for (e, t, col) in st[2]:
+                be.g_polygon(st[1], t, colour=col)
         elif st[0] == "object":
             _, sc, rt, obj = st
             m = P.make_matrix((0, 0, 0, 0, 0, 0), obj, 0)
@@ -409,6 +442,25 @@ def run_wire_case(steps, be):
             for l in st[1]:
                 be.g_line(l[0:3], l[3:6], int(l[6]), 255, 255, 255)
     return be.cbuf().copy(), be.zbuf().copy()
+
+
+def _textures_of(steps):
+    for st in steps:
+        if st[0] == "object" and st[1].textures:
+            return st[1].textures
+    return []
+
+
+def window_kats():
+    """Frames under smaller clip windows drawn by the reference build: digests."""
+    out = {}
+    for name, steps in window_cases().items():
+        r = R.Ref(WIRE_W, WIRE_H)
+        for hnd, (tex, lg) in enumerate(_textures_of(steps)):
+            r.set_texture(hnd, tex, lg)
+        c, z = run_wire_case(steps, r)
+        out[name] = dict(colour=S.frame_digest(c), depth=S.frame_digest(z), drawn=int((c != c[0, 0]).sum()))
+    return out
 
 
 def wire_kats():
@@ -436,6 +488,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "shade_kats.npz"), **shade_kats())
     np.savez_compressed(os.path.join(HERE, "normals_kats.npz"), **normals_kats())
     json.dump(wire_kats(), open(os.path.join(HERE, "wire_kats.json"), "w"), indent=1, sort_keys=True)
+    json.dump(window_kats(), open(os.path.join(HERE, "window_kats.json"), "w"), indent=1, sort_keys=True)
     if not os.path.isdir(REFDIR):
         raise SystemExit("needs /root/reference (run in the build container)")
     np.savez_compressed(os.path.join(HERE, "stage_kats.npz"), **stage_kats())

@@ -10,8 +10,10 @@ import pytest
 
 from raytracing_amd import scenes as S
 
+sys.path.insert(0, os.path.dirname(__file__))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
 import make_golden as MG  # noqa: E402
+from gpu_steps import run_gpu  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "wire_kats.json")))
@@ -27,33 +29,6 @@ def env():
     import oracle.port as P
     from raytracing_amd import gpu as G
     return P, G
-
-
-def run_gpu(P, ctx, steps, device_arrays=False):
-    import torch
-    for st in steps:
-        if st[0] == "clear":
-            ctx.clear(P.cl_light(st[1], 255, 255, 255))
-        elif st[0] == "object":
-            _, sc, rt, obj = st
-            m = P.make_matrix((0, 0, 0, 0, 0, 0), obj, 0)
-            if device_arrays:
-                d = [None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
-                     for a in (sc.verts, sc.polys, sc.polyverts, sc.polyaux)]
-                ctx.submit_object_dev(d[0], d[1], d[2], rt, sc.log_focus, d_polyaux=d[3], matrix=m)
-                ctx.flush()
-            else:
-                ctx.submit_object(sc.verts, sc.polys, sc.polyverts, rt, sc.log_focus, polyaux=sc.polyaux, matrix=m)
-        else:
-            l = st[1].copy()
-            l[:, 6] = [P.cl_light(int(c), 255, 255, 255) for c in l[:, 6]]
-            if device_arrays:
-                d = torch.from_numpy(l).cuda()
-                ctx.submit_lines_dev(d)
-                ctx.flush()
-            else:
-                ctx.submit_lines(l)
-    return ctx.readback()
 
 
 @pytest.mark.parametrize("pipelined", [True, False])
