@@ -203,3 +203,11 @@ class Ref:
         """C_init_clipping; stays in force for this library (a process-wide global of the reference)"""
         self.L.ltref_init_clipping(int(minx), int(miny), int(maxx), int(maxy))
 
+    def set_gate(self, indices, verts, log_focus, start):
+        """the real M_set_gate from the window `start` -> (return value, window left behind)"""
+        idx, v, st = _i32(indices).copy(), _i32(verts).reshape(-1, 4).copy(), _i32(start)
+        out = np.zeros(4, np.int32)
+        self.L.ltref_set_gate.restype = C.c_int
+        rc = self.L.ltref_set_gate(idx.shape[0] - 1, _p(idx), _p(v), int(log_focus), _p(st), _p(out))
+        return rc, out
+

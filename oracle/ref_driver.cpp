@@ -238,6 +238,22 @@ void ltref_init_clipping(int minx,int miny,int maxx,int maxy)
  C_init_clipping(minx,miny,maxx,maxy);
 }
 
+/* The real M_set_gate (EngBase.cpp:567-629) on view-space vertices, starting from the window
+ * (minx, miny, maxx, maxy); bounds[4] receives the window it leaves (C_get_bounds).  The
+ * full-screen window is restored afterwards. */
+int ltref_set_gate(int no_edges,int *indices,int *vertices,int log_focus,const int *start,int *bounds)
+{
+ struct M_gate g;
+ int rc;
+ g.m_volume=NULL; g.m_no_edges=no_edges; g.m_vertices=indices;
+ M_set_camera(0,0,0,0,0,0,log_focus);
+ C_init_clipping(start[0],start[1],start[2],start[3]);
+ rc=M_set_gate(&g,vertices);
+ C_get_bounds(bounds,bounds+1,bounds+2,bounds+3);
+ C_init_clipping(C_X_CLIPPING_MIN,C_Y_CLIPPING_MIN,C_X_CLIPPING_MAX,C_Y_CLIPPING_MAX);
+ return rc;
+}
+
 /* The real G_line (GraphicsBase.cpp:165-253); v1, v2 = projected {X, Y, Z} */
 void ltref_g_line(int *v1,int *v2,int colour,int r,int g,int b)
 {

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <utility>
 #include <vector>
 
 // ------------------------------------------------------------------ state
@@ -319,6 +320,126 @@ int C_set_bounds(int minx, int miny, int maxx, int maxy)
     return 1;
 }
 
+// ------------------------------------------------------------------ host-side clippers and projection
+//
+// The reference's callers may use these directly (Clipper.h:29-35, Trans.h:42,62); the GPU
+// path has its own copies inside the set-up kernels.  M_set_gate below is built on them.
+
+int C_2D_clipping = 0;                               // Clipp2D.cpp:22
+int C_3D_clipping = 0;                               // Clipp3D.cpp
+
+namespace {
+
+#define LT_C_MAX_DIMENSIONS 8                        // Clipper.h:16
+#define LT_C_Z_CLIPPING_MIN 10                       // Clipper.h:18
+
+// One binary-search clipper behind the three line-clipping entry points.  The two ends are
+// ordered along `axis`; an end at or beyond a bound is replaced by the point where halving
+// the segment -- every dimension alike, floor of the mean -- lands exactly on the bound
+// (Clipp2D.cpp:118-152, Clipp3D.cpp:91-104).  As in the reference the caller's pointer is
+// redirected to one of the entry point's static stores, valid until its next call.
+int clip_segment(int **vertex1, int **vertex2, int dimension, int axis, int bmin, int bmax, bool both,
+                 int (*store)[LT_C_MAX_DIMENSIONS], int *first_moved)
+{
+    *first_moved = 0;
+    const bool swapped = !((*vertex1)[axis] < (*vertex2)[axis]);
+    int **lo = swapped ? vertex2 : vertex1, **hi = swapped ? vertex1 : vertex2;
+    if (both ? ((*lo)[axis] >= bmax || (*hi)[axis] <= bmin) : ((*hi)[axis] <= bmin)) return 0;
+    for (int side = 0; side < (both ? 2 : 1); side++) {
+        const int bound = side == 0 ? bmin : bmax;
+        if (side == 0 ? !((*lo)[axis] <= bmin) : !((*hi)[axis] >= bmax)) continue;
+        // side 0 searches from the low end, side 1 from the high end
+        int *m = store[3 * side + (side == 0 ? 0 : 1)], *l, *r;
+        if (side == 0) { r = store[1]; l = store[2]; memcpy(m, *lo, sizeof(int) * dimension); memcpy(r, *hi, sizeof(int) * dimension); }
+        else           { l = store[3]; r = store[5]; memcpy(l, *lo, sizeof(int) * dimension); memcpy(m, *hi, sizeof(int) * dimension); }
+        bool below = side == 0;                      // is the search point on the low side of the bound?
+        while (m[axis] != bound) {
+            if (below) std::swap(l, m); else std::swap(r, m);
+            for (int i = 0; i < dimension; i++) m[i] = wadd(l[i], r[i]) >> 1;
+            below = m[axis] < bound;
+        }
+        if (side == 0) { *lo = m; *first_moved = swapped ? 0 : 1; }
+        else           { *hi = m; *first_moved |= swapped ? 1 : 0; }
+    }
+    return 1;
+}
+
+// C_polygon_x_clipping / C_polygon_z_clipping (Clipp2D.cpp:247-275, Clipp3D.cpp:129-159): every
+// edge through the line clipper; an edge whose first end moved contributes both ends, any
+// other surviving edge its second end; the first tuple written closes the polygon.
+template <typename F>
+int clip_polygon_host(int *from, int *to, int dimension, int length, F line_clip, const int *moved_flag)
+{
+    int n = 0;
+    int *out = to;
+    for (int i = 0; i < length; i++, from += dimension) {
+        int *v1 = from, *v2 = from + dimension;
+        if (!line_clip(&v1, &v2, dimension)) continue;
+        if (*moved_flag) { memcpy(out, v1, sizeof(int) * dimension); out += dimension; n++; }
+        memcpy(out, v2, sizeof(int) * dimension); out += dimension; n++;
+    }
+    memcpy(out, to, sizeof(int) * dimension);
+    return n;
+}
+
+}  // namespace
+
+int C_line_x_clipping(int **vertex1, int **vertex2, int dimension)
+{
+    static int store[6][LT_C_MAX_DIMENSIONS];
+    return clip_segment(vertex1, vertex2, dimension, 0, Cb[0], Cb[2], true, store, &C_2D_clipping);
+}
+
+int C_line_y_clipping(int **vertex1, int **vertex2, int dimension)
+{
+    static int store[6][LT_C_MAX_DIMENSIONS];
+    return clip_segment(vertex1, vertex2, dimension, 1, Cb[1], Cb[3], true, store, &C_2D_clipping);
+}
+
+int C_line_z_clipping(int **vertex1, int **vertex2, int dimension)
+{
+    static int store[6][LT_C_MAX_DIMENSIONS];
+    return clip_segment(vertex1, vertex2, dimension, 2, LT_C_Z_CLIPPING_MIN, 0, false, store, &C_3D_clipping);
+}
+
+int C_polygon_x_clipping(int *from, int *to, int dimension, int length)
+{
+    return clip_polygon_host(from, to, dimension, length, C_line_x_clipping, &C_2D_clipping);
+}
+
+int C_polygon_z_clipping(int *from, int *to, int dimension, int length)
+{
+    return clip_polygon_host(from, to, dimension, length, C_line_z_clipping, &C_3D_clipping);
+}
+
+// Clipp3D.cpp:46-58: 0 outside the view pyramid, -1 across the near plane, 1 in front of it
+int C_volume_clipping(int *min, int *max)
+{
+    if (max[2] < min[0] || max[2] < min[1] || max[2] < -max[0] || max[2] < -max[1] || max[2] <= LT_C_Z_CLIPPING_MIN) return 0;
+    return min[2] < LT_C_Z_CLIPPING_MIN ? -1 : 1;
+}
+
+// TransBs.cpp:416-434 (_Z_BUFFER_): X' = (X << log_focus) / Z + W/2, Y' likewise, Z' = -0x7ffff / Z,
+// 64-bit intermediates truncated to int; the other values of a tuple are passed on.
+void T_perspective(int *from, int *to, int dimension, int length, int log_focus)
+{
+    for (int i = 0; i < length; i++, from += dimension, to += dimension) {
+        const long long z = from[2];
+        to[0] = wadd((int)(((long long)from[0] * ((long long)1 << log_focus)) / z), g_w / 2);
+        to[1] = wadd((int)(((long long)from[1] * ((long long)1 << log_focus)) / z), g_h / 2);
+        to[2] = (int)(-0x7ffffLL / z);
+        for (int j = 3; j < dimension; j++) to[j] = from[j];
+    }
+}
+
+// TransLn.cpp:218-223
+int T_normal_z_negative(int *from1, int *from2, int *from3)
+{
+    const long long a = (long long)(int)((unsigned)from2[0] - (unsigned)from1[0]) * (int)((unsigned)from3[1] - (unsigned)from1[1]);
+    const long long b = (long long)(int)((unsigned)from2[1] - (unsigned)from1[1]) * (int)((unsigned)from3[0] - (unsigned)from1[0]);
+    return a - b < 0;
+}
+
 // ------------------------------------------------------------------ engine (EngBase.cpp / EngPoly.cpp)
 
 void M_init_rendering(int type) { g_rendering_type = type; }
@@ -360,6 +481,40 @@ void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *
     tmp.m_vertices = recs.data();
     flatten_polygon(&tmp, base, q_polys, q_aux, q_pv);
     if (poly->m_no_edges > q_max_edges) q_max_edges = poly->m_no_edges;
+}
+
+// EngBase.cpp:567-629: the clip window becomes its intersection with the screen extent of a
+// portal polygon (view-space vertices, closed index list); 0 if the gate is behind the
+// viewer, faces away or leaves no window.
+int M_set_gate(struct M_gate *gate, int *vertices)
+{
+    int original1[G_MAX_POLYGON_VERTICES * LT_C_MAX_DIMENSIONS], original2[G_MAX_POLYGON_VERTICES * LT_C_MAX_DIMENSIONS];
+    int perspective[G_MAX_POLYGON_VERTICES * LT_C_MAX_DIMENSIONS];
+    int number = gate->m_no_edges;
+    if (number + 1 > G_MAX_POLYGON_VERTICES) HW_error((char *)"(Engine) a gate of more than 15 edges.\n");
+    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (int i = 0; i <= number; i++)
+        for (int j = 0; j < 3; j++) {
+            const int v = vertices[gate->m_vertices[i] * T_LNG_VECTOR + j];
+            original1[i * 3 + j] = v;
+            if (v > mx[j]) mx[j] = v;
+            if (v < mn[j]) mn[j] = v;
+        }
+    const int cnd = C_volume_clipping(mn, mx);
+    if (cnd == 0) return 0;
+    int *clipped = original1;
+    if (cnd == -1) { number = C_polygon_z_clipping(original1, original2, 3, number); clipped = original2; }
+    T_perspective(clipped, perspective, 3, number + 1, M_camera_log_focus);
+    if (!T_normal_z_negative(perspective, perspective + 3, perspective + 6)) return 0;
+    int nminx = INT_MAX, nminy = INT_MAX, nmaxx = INT_MIN, nmaxy = INT_MIN;
+    for (int i = 0; i < number; i++) {
+        const int x = perspective[i * 3], y = perspective[i * 3 + 1];
+        if (x > nmaxx) nmaxx = x;
+        if (x < nminx) nminx = x;
+        if (y > nmaxy) nmaxy = y;
+        if (y < nminy) nminy = y;
+    }
+    return C_set_bounds(nminx, nminy, nmaxx, nmaxy);
 }
 
 // The list of normals under construction: MI_add_tuple (EngPoly.cpp:46-63) compares X Y Z

@@ -58,11 +58,22 @@ void T_set_self_rotation(unsigned char alp, unsigned char bet, unsigned char gam
 void T_set_world_rotation(unsigned char alp, unsigned char bet, unsigned char gam);
 void T_cancatinate_self_world(int addx, int addy, int addz);
 void T_cancatinated_rotation(int *from, int *to, int length);
+void T_perspective(int *from, int *to, int dimension, int length, int log_focus);    // Trans.h:62
+int T_normal_z_negative(int *from1, int *from2, int *from3);                         // Trans.h:42
 
 // ---- Clipper.h:26-28
 void C_init_clipping(int minx, int miny, int maxx, int maxy);
 void C_get_bounds(int *minx, int *miny, int *maxx, int *maxy);
 int C_set_bounds(int minx, int miny, int maxx, int maxy);
+// Clipper.h:29-35, on the host (the GPU path has its own copies): binary-search clippers that
+// redirect the caller's pointers to static stores, and the polygon clippers built on them
+extern int C_2D_clipping, C_3D_clipping;
+int C_line_x_clipping(int **vertex1, int **vertex2, int dimension);
+int C_line_y_clipping(int **vertex1, int **vertex2, int dimension);
+int C_polygon_x_clipping(int *from, int *to, int dimension, int length);
+int C_volume_clipping(int *min, int *max);
+int C_line_z_clipping(int **vertex1, int **vertex2, int dimension);
+int C_polygon_z_clipping(int *from, int *to, int dimension, int length);
 
 // ---- Engine.h:80-90, 148-152, 209-238, 435-460
 #define M_WIRE 0x01
@@ -117,6 +128,15 @@ struct M_light {
     int m_parameter[4];
     int m_red, m_green, m_blue;
 };
+
+// Engine.h:342-350, EngBase.cpp:567-629: narrows the clip window to a portal polygon's extent
+struct M_volume_object;
+struct M_gate {
+    struct M_volume_object *m_volume;
+    int m_no_edges;
+    int *m_vertices;            // closed list of vertex indices
+};
+int M_set_gate(struct M_gate *gate, int *vertices);
 
 // EngPoly.cpp:355-459 (no BSP ordering with a depth buffer): gives every M_PLANNAR / M_CURVED
 // polygon its m_normals indices and the object its list of normals; m_normals must be NULL

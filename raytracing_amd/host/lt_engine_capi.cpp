@@ -23,6 +23,21 @@ void lte_flush(void) { HW_flush(); }
 int lte_cl_light(int c, int r, int g, int b) { return CL_light(c, r, g, b); }
 void lte_init_clipping(int minx, int miny, int maxx, int maxy) { C_init_clipping(minx, miny, maxx, maxy); }
 int lte_set_bounds(int minx, int miny, int maxx, int maxy) { return C_set_bounds(minx, miny, maxx, maxy); }
+// host-only use (no GPU context): screen size and full-screen window for the clippers and T_perspective
+void lte_screen_size(int w, int h) { HW_init_screen_size(w, h); C_init_clipping(0, 0, w - 1, h - 1); }
+int lte_set_gate(int no_edges, int *indices, int *vertices, int log_focus)
+{
+    M_gate g;
+    g.m_volume = nullptr; g.m_no_edges = no_edges; g.m_vertices = indices;
+    M_set_camera(0, 0, 0, 0, 0, 0, log_focus);
+    return M_set_gate(&g, vertices);
+}
+void lte_get_bounds(int *b) { C_get_bounds(b, b + 1, b + 2, b + 3); }
+int lte_polygon_clipping(int axis, int *from, int *to, int dim, int len)
+{
+    return axis == 0 ? C_polygon_x_clipping(from, to, dim, len) : C_polygon_z_clipping(from, to, dim, len);
+}
+void lte_perspective(int *from, int *to, int dim, int len, int log_focus) { T_perspective(from, to, dim, len, log_focus); }
 void lte_g_line(int *v1, int *v2, int colour, int r, int g, int b) { G_line(v1, v2, colour, r, g, b); }
 
 static void fill(M_polygon *p, M_texture *texs, const int *polys, const int *aux, int *pv, int i)

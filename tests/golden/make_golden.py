@@ -396,6 +396,30 @@ def wire_cases():
     return cases
 
 
+def gate_inputs(n=200, seed=5, w=WIRE_W, h=WIRE_H):
+    """n portal polygons in view space with the window each is applied to:
+    list of (indices int32[e+1], verts int32[e][4], start window int32[4])"""
+    rng = S.Rng(seed)
+    out = []
+    for _ in range(n):
+        e = int(rng.ints(3, 6, 1)[0])
+        v = np.zeros((e, 4), np.int32)
+        v[:, :2] = rng.ints(-400, 400, e * 2).reshape(-1, 2)
+        v[:, 2] = rng.ints(-50, 900, e)
+        idx = np.array(list(range(e)) + [0], np.int32)
+        start = np.array([int(rng.ints(0, 60, 1)[0]), int(rng.ints(0, 40, 1)[0]), int(rng.ints(120, w - 1, 1)[0]),
+                          int(rng.ints(90, h - 1, 1)[0])], np.int32)
+        out.append((idx, v, start))
+    return out
+
+
+def gate_kats():
+    """M_set_gate of the reference build on gate_inputs(): return values and windows left behind."""
+    r = R.Ref(WIRE_W, WIRE_H)
+    res = [r.set_gate(idx, v, 7, start) for (idx, v, start) in gate_inputs()]
+    return dict(rc=np.array([a for a, _ in res], np.int32), bounds=np.array([b for _, b in res], np.int32))
+
+
 def window_cases():
     """Frames drawn under clip windows smaller than the screen (C_init_clipping): steps as in
     wire_cases plus ("window", (minx, miny, maxx, maxy)) and ("gpolys", kind, polygons of
@@ -489,6 +513,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "normals_kats.npz"), **normals_kats())
     json.dump(wire_kats(), open(os.path.join(HERE, "wire_kats.json"), "w"), indent=1, sort_keys=True)
     json.dump(window_kats(), open(os.path.join(HERE, "window_kats.json"), "w"), indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "gate_kats.npz"), **gate_kats())
     if not os.path.isdir(REFDIR):
         raise SystemExit("needs /root/reference (run in the build container)")
     np.savez_compressed(os.path.join(HERE, "stage_kats.npz"), **stage_kats())
