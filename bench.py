@@ -393,7 +393,7 @@ def main():
         vr = valu_roofline(args.workload, sc.n_polys, dom, dom_ms)
         if vr:
             out["roofline_valu"] = vr
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # the CPU legs run beside the one-GPU line only
             base, oc, oz = cpu_baseline(sc, passes=2 if sc.n_polys <= 2_000_000 else 1)
             c, z = ctx.readback()
             out["cpu_baseline"] = base
