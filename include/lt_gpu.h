@@ -216,6 +216,17 @@ int lt_shade_object(lt_ctx *ctx, const int32_t s9[9], int32_t x, int32_t y, int3
 int lt_submit_lines_dev(lt_ctx *ctx, const int32_t *d_lines, int n);
 int lt_submit_lines(lt_ctx *ctx, const int32_t *lines, int n);
 
+/* The shading loop of M_shade_bicubic (EngBcub.cpp:314-325): M_shade_vertex
+ * (EngBase.cpp:220-288) for n points that are already in world space -- the reference
+ * evaluates them from the rotated and translated control points -- with their normals
+ * rotated by s9 here (T_self_rotation, EngBcub.cpp:291).  d_points, d_normals, d_rgb are
+ * int32[n][4]; d_rgb[i] = {R, G, B, 0}.  Errors as lt_shade_object_dev. */
+int lt_shade_points_dev(lt_ctx *ctx, const int32_t s9[9], const int32_t *d_points, const int32_t *d_normals, int n,
+                        const lt_light *lights, int nlights, int32_t *d_rgb);
+/* The same on host arrays; rgb is filled before the call returns. */
+int lt_shade_points(lt_ctx *ctx, const int32_t s9[9], const int32_t *points, const int32_t *normals, int n,
+                    const lt_light *lights, int nlights, int32_t *rgb);
+
 /* The plane normals of M_init_polygon_object (EngPoly.cpp:392-398): for every polygon,
  * T_normal_plane (TransLn.cpp:150-171) of the vertices of its first three records:
  * d_plane_normals[p] = {nx, ny, nz, 0}, unit length scaled by 1<<7.  These are the m_normals

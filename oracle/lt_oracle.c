@@ -1063,3 +1063,172 @@ int lto_init_normals(const i32 *verts,int nv,const i32 *polys,const i32 *types,i
     free(plane); free(have);
     return rc<0?rc:count;
 }
+
+/* ------------------------------------------------------------------ bicubic patches (EngBcub.cpp)
+ *
+ * A patch is 16 control points int32[16][4]; it is tessellated into (size-1)^2 squares,
+ * size = (1 << log_render_size) + 1, by recursive halving of the Bezier control polygons in
+ * integer arithmetic, and every square goes through M_render_polygon with per-point
+ * colours and texture coordinates. */
+
+#define LTO_M_PB 8                           /* Engine.h:78 */
+#define LTO_MAX_RENDER_SIZE 33               /* Engine.h:275 */
+
+static i32 half_sum(i32 a,i32 b){ return tdiv(wadd(a,b),2); }
+
+/* MI_evaluate_bezier_points, EngBcub.cpp:113-152; the top-level call with `rendering` shifts
+ * its four controls left by M_PB in place, as the reference does */
+static void bezier_points(i32 *b1,i32 *b2,i32 *b3,i32 *b4,i32 *points,int dim,int length,int top,int rendering)
+{
+    i32 b12[3],b23[3],b34[3],b123[3],b234[3],*b1234;
+    int k;
+    if(top)
+    {
+        if(rendering)
+            for(k=0;k<3;k++)
+            { b1[k]=wshl(b1[k],LTO_M_PB); b2[k]=wshl(b2[k],LTO_M_PB); b3[k]=wshl(b3[k],LTO_M_PB); b4[k]=wshl(b4[k],LTO_M_PB); }
+        memcpy(points,b1,3*sizeof(i32));
+        memcpy(points+(length-1)*dim,b4,3*sizeof(i32));
+    }
+    if(length>2)
+    {
+        b1234=points+(length/2)*dim;
+        for(k=0;k<3;k++)
+        {
+            b12[k]=half_sum(b1[k],b2[k]); b23[k]=half_sum(b2[k],b3[k]); b34[k]=half_sum(b3[k],b4[k]);
+            b123[k]=half_sum(b12[k],b23[k]); b234[k]=half_sum(b23[k],b34[k]);
+            b1234[k]=half_sum(b123[k],b234[k]);
+        }
+        bezier_points(b1,b12,b123,b1234,points,dim,length/2+1,0,rendering);
+        bezier_points(b1234,b234,b34,b4,b1234,dim,length/2+1,0,rendering);
+    }
+}
+
+/* MI_evaluate_bezier_tangents, EngBcub.cpp:163-196 */
+static void bezier_tangents(const i32 *b1,const i32 *b2,const i32 *b3,const i32 *b4,i32 *tangents,int dim,int length,int top)
+{
+    i32 b12[3],b23[3],b34[3],b123[3],b234[3],b1234[3],*mid;
+    int k;
+    if(top)
+        for(k=0;k<3;k++)
+        { tangents[k]=wsub(b2[k],b1[k]); tangents[(length-1)*dim+k]=wsub(b4[k],b3[k]); }
+    if(length>2)
+    {
+        mid=tangents+(length/2)*dim;
+        for(k=0;k<3;k++)
+        {
+            b12[k]=half_sum(b1[k],b2[k]); b23[k]=half_sum(b2[k],b3[k]); b34[k]=half_sum(b3[k],b4[k]);
+            b123[k]=half_sum(b12[k],b23[k]); b234[k]=half_sum(b23[k],b34[k]);
+            mid[k]=wsub(b234[k],b123[k]);
+            b1234[k]=half_sum(b123[k],b234[k]);
+        }
+        bezier_tangents(b1,b12,b123,b1234,tangents,dim,length/2+1,0);
+        bezier_tangents(b1234,b234,b34,b4,mid,dim,length/2+1,0);
+    }
+}
+
+/* the four curves across the patch, then one curve per column: points[size][size][4] */
+static void patch_points(i32 *c,i32 *points,int size,int rendering)
+{
+    i32 t1[LTO_MAX_RENDER_SIZE*4],t2[LTO_MAX_RENDER_SIZE*4],t3[LTO_MAX_RENDER_SIZE*4],t4[LTO_MAX_RENDER_SIZE*4];
+    int i;
+    bezier_points(c,c+16,c+32,c+48,t1,4,size,1,rendering);
+    bezier_points(c+4,c+20,c+36,c+52,t2,4,size,1,rendering);
+    bezier_points(c+8,c+24,c+40,c+56,t3,4,size,1,rendering);
+    bezier_points(c+12,c+28,c+44,c+60,t4,4,size,1,rendering);
+    for(i=0;i<size;i++)
+        bezier_points(t1+i*4,t2+i*4,t3+i*4,t4+i*4,points+(size_t)i*size*4,4,size,1,0);
+}
+
+/* M_init_bicubic, EngBcub.cpp:204-265: normals[size*size][4] (three words each are written).
+ * Returns 0, -1 where the reference stops on a zero-length normal, -2 for a size it refuses. */
+int lto_init_bicubic(const i32 *controls,int log_render_size,i32 *normals)
+{
+    static i32 tan1[LTO_MAX_RENDER_SIZE*LTO_MAX_RENDER_SIZE*4],tan2[LTO_MAX_RENDER_SIZE*LTO_MAX_RENDER_SIZE*4];
+    i32 c[64],t1[LTO_MAX_RENDER_SIZE*4],t2[LTO_MAX_RENDER_SIZE*4],t3[LTO_MAX_RENDER_SIZE*4],t4[LTO_MAX_RENDER_SIZE*4];
+    static const i32 origin[3]={0,0,0};
+    int i,size=(1<<log_render_size)+1;
+    if(log_render_size<0||size>=LTO_MAX_RENDER_SIZE) return -2;
+    memcpy(c,controls,sizeof c);
+    bezier_points(c,c+4,c+8,c+12,t1,4,size,1,0);
+    bezier_points(c+16,c+20,c+24,c+28,t2,4,size,1,0);
+    bezier_points(c+32,c+36,c+40,c+44,t3,4,size,1,0);
+    bezier_points(c+48,c+52,c+56,c+60,t4,4,size,1,0);
+    for(i=0;i<size;i++) bezier_tangents(t1+i*4,t2+i*4,t3+i*4,t4+i*4,tan1+i*4,4*size,size,1);
+    bezier_points(c,c+16,c+32,c+48,t1,4,size,1,0);
+    bezier_points(c+4,c+20,c+36,c+52,t2,4,size,1,0);
+    bezier_points(c+8,c+24,c+40,c+56,t3,4,size,1,0);
+    bezier_points(c+12,c+28,c+44,c+60,t4,4,size,1,0);
+    for(i=0;i<size;i++) bezier_tangents(t1+i*4,t2+i*4,t3+i*4,t4+i*4,tan2+(size_t)i*size*4,4,size,1);
+    for(i=0;i<size*size;i++)                 /* T_normal_vectors = T_normal_plane from the origin */
+        if(!lto_normal_plane(origin,tan1+i*4,tan2+i*4,normals+i*4)) return -1;
+    return 0;
+}
+
+/* M_shade_bicubic, EngBcub.cpp:271-326: intensities[size*size][3]; returns the number of
+ * (point, light) pairs skipped for a zero-length light vector, -2 for a refused size. */
+int lto_shade_bicubic(const i32 *s9,i32 x,i32 y,i32 z,const i32 *controls,int log_render_size,const i32 *normals,
+                      const i32 *lights,int nl,i32 *intensities)
+{
+    static i32 points[LTO_MAX_RENDER_SIZE*LTO_MAX_RENDER_SIZE*4];
+    i32 c[64],wn[3];
+    int i,skipped=0,size=(1<<log_render_size)+1;
+    if(log_render_size<0||size>LTO_MAX_RENDER_SIZE) return -2;
+    for(i=0;i<16;i++)
+    {
+        self_rotate(s9,controls+i*4,c+i*4);
+        c[i*4]=wadd(c[i*4],x); c[i*4+1]=wadd(c[i*4+1],y); c[i*4+2]=wadd(c[i*4+2],z); c[i*4+3]=0;
+    }
+    patch_points(c,points,size,0);
+    for(i=0;i<size*size;i++)
+    {
+        self_rotate(s9,normals+i*4,wn);
+        skipped+=shade_vertex(intensities+i*3,points+i*4,wn,nl,lights);
+    }
+    return skipped;
+}
+
+/* M_render_bicubic, EngBcub.cpp:332-403, after the caller has built the matrix m
+ * (T_set_self_rotation + T_cancatinate_self_world): one M_render_polygon per square
+ * (MI_render_square, :68-102).  tex = texture handle or -1.  Returns 0, -2 for a refused size,
+ * -3 where the reference stops with "Too small a texture to fit onto a bicubic". */
+int lto_render_bicubic(lto_ctx *ctx,const i32 *m,const i32 *controls,int log_render_size,i32 colour,
+                       int log_texture_space_size,int tex,const i32 *intensities,int render_type,int log_focus,
+                       int force_linear)
+{
+    static i32 points[LTO_MAX_RENDER_SIZE*LTO_MAX_RENDER_SIZE*4];
+    static const int corner[5]={2,3,1,0,2};  /* M_square_v, EngBcub.cpp:49-56 */
+    i32 c[64];
+    int i,k,size=(1<<log_render_size)+1,incr=log_texture_space_size-log_render_size,step,max;
+    if(log_render_size<0||size>LTO_MAX_RENDER_SIZE) return -2;
+    if(incr<=0) return -3;
+    memset(c,0,sizeof c);
+    lto_transform(m,controls,c,16);
+    step=1<<incr; max=1<<log_texture_space_size;
+    patch_points(c,points,size,1);
+    ctx->log_focus=log_focus;
+    for(i=0;i<size*size;i++)
+    {
+        int no[4];
+        i32 vert[16],poly[4],aux[4],rec[30];
+        if(i%size==size-1||i/size==size-1) continue;
+        no[0]=i; no[1]=i+1; no[2]=i+size; no[3]=i+size+1;
+        for(k=0;k<4;k++)
+        {
+            vert[k*4]=points[no[k]*4]>>LTO_M_PB; vert[k*4+1]=points[no[k]*4+1]>>LTO_M_PB; vert[k*4+2]=points[no[k]*4+2]>>LTO_M_PB;
+            vert[k*4+3]=0;
+        }
+        for(k=0;k<5;k++)
+        {
+            int p=no[corner[k]];
+            rec[k*6]=corner[k];
+            rec[k*6+1]=intensities[p*3]; rec[k*6+2]=intensities[p*3+1]; rec[k*6+3]=intensities[p*3+2];
+            rec[k*6+4]=(p%size)*step; rec[k*6+5]=max-(p/size)*step;      /* the grid of :366-373 */
+        }
+        poly[0]=colour; poly[1]=tex; poly[2]=4; poly[3]=0;
+        aux[0]=intensities[no[0]*3]; aux[1]=intensities[no[0]*3+1]; aux[2]=intensities[no[0]*3+2];
+        aux[3]=LTO_M_QUAD_XY|(incr<<8);
+        render_polygon(ctx,vert,poly,aux,rec,render_type,force_linear);
+    }
+    return 0;
+}

@@ -65,6 +65,13 @@ def lib():
         L.lto_shade_polys.restype = C.c_int
         L.lto_shade_polys.argtypes = ([C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p, C.c_int] * 2 + [C.c_void_p, C.c_int]
                                       + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p])
+        L.lto_init_bicubic.restype = C.c_int
+        L.lto_init_bicubic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.lto_shade_bicubic.restype = C.c_int
+        L.lto_shade_bicubic.argtypes = [C.c_void_p] + [C.c_int32] * 3 + [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.lto_render_bicubic.restype = C.c_int
+        L.lto_render_bicubic.argtypes = ([C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int32, C.c_int, C.c_int, C.c_void_p]
+                                         + [C.c_int] * 3)
         L.lto_set_clip_window.restype = None
         L.lto_set_clip_window.argtypes = [C.c_void_p] + [C.c_int32] * 4
         L.lto_g_line.restype = None
@@ -184,6 +191,26 @@ class Oracle:
         """G_line on projected {X, Y, Z} end points"""
         a, bb = _i32(v1), _i32(v2)
         self.L.lto_g_line(self.c, _p(a), _p(bb), int(colour), int(r), int(g), int(b))
+
+    def bicubic(self, controls, log_render_size, colour, log_texture_space_size, tex, pos, ang, lights, render_type,
+                log_focus, force_linear=1, variant=0):
+        """M_init_bicubic + M_shade_bicubic + M_render_bicubic of one patch into this frame ->
+        (normals int32[size*size][4], intensities int32[size*size][3])"""
+        c, li = _i32(controls).reshape(16, 4), _i32(lights).reshape(-1, 8)
+        size = (1 << log_render_size) + 1
+        normals = np.zeros((size * size, 4), np.int32)
+        inten = np.zeros((size * size, 3), np.int32)
+        if self.L.lto_init_bicubic(_p(c), log_render_size, _p(normals)) != 0:
+            raise ValueError("M_init_bicubic stops on this patch")
+        s9 = self_matrix(*ang, variant=variant)
+        if self.L.lto_shade_bicubic(_p(s9), int(pos[0]), int(pos[1]), int(pos[2]), _p(c), log_render_size, _p(normals),
+                                    _p(li), li.shape[0], _p(inten)) != 0:
+            raise ValueError("M_shade_bicubic stops on this patch")
+        m = make_matrix((0, 0, 0, 0, 0, 0), (*ang, *pos), variant)
+        if self.L.lto_render_bicubic(self.c, _p(m), _p(c), log_render_size, int(colour), log_texture_space_size, int(tex),
+                                     _p(inten), int(render_type), int(log_focus), int(force_linear)) != 0:
+            raise ValueError("M_render_bicubic stops on this patch")
+        return normals, inten
 
     def render_polys(self, viewverts, polys, polyaux, polyverts, render_type, log_focus, force_linear=0):
         vv, po, pv = _i32(viewverts), _i32(polys), _i32(polyverts)

@@ -211,3 +211,16 @@ class Ref:
         rc = self.L.ltref_set_gate(idx.shape[0] - 1, _p(idx), _p(v), int(log_focus), _p(st), _p(out))
         return rc, out
 
+    def bicubic(self, controls, log_render_size, colour, log_texture_space_size, tex, pos, ang, lights, render_type,
+                log_focus, force_linear=1):
+        """the real M_init_bicubic + M_shade_bicubic + M_render_bicubic of one patch into the current
+        frame -> (normals int32[size*size][4] (three words defined), intensities int32[size*size][3])"""
+        c, li = _i32(controls).reshape(16, 4), _i32(lights).reshape(-1, 8)
+        size = (1 << log_render_size) + 1
+        normals = np.zeros((size * size, 4), np.int32)
+        inten = np.zeros((size * size, 3), np.int32)
+        self.L.ltref_bicubic(_p(c), int(log_render_size), C.c_int(colour), int(log_texture_space_size), int(tex),
+                             int(pos[0]), int(pos[1]), int(pos[2]), int(ang[0]), int(ang[1]), int(ang[2]), _p(li), li.shape[0],
+                             int(render_type), int(log_focus), int(force_linear), _p(normals), _p(inten))
+        return normals, inten
+

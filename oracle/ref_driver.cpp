@@ -254,6 +254,43 @@ int ltref_set_gate(int no_edges,int *indices,int *vertices,int log_focus,const i
  return rc;
 }
 
+/* The real M_init_bicubic, M_shade_bicubic and M_render_bicubic (EngBcub.cpp:204-403) on one
+ * patch: controls[16][4]; normals[size*size][4] and intensities[size*size][3] are copied out;
+ * the patch is drawn with the current frame, rendering type `type`, camera at the origin.
+ * lights[nl][8] as in ltref_shade_object. */
+void ltref_bicubic(const int *controls,int log_render_size,int colour,int log_texture_space_size,int tex,
+                   int x,int y,int z,int alp,int bet,int gam,const int *lights,int nl,
+                   int type,int log_focus,int force_linear,int *normals,int *intensities)
+{
+ struct M_bicubic b;
+ std::vector<struct M_light> lstore(nl);
+ std::vector<struct M_light*> lptrs(nl);
+ int size=(1<<log_render_size)+1,old=M_force_linear_tmapping;
+ for(int j=0;j<nl;j++)
+ {
+  lstore[j].m_type=lights[j*8];
+  for(int k=0;k<4;k++) lstore[j].m_parameter[k]=lights[j*8+1+k];
+  lstore[j].m_red=lights[j*8+5]; lstore[j].m_green=lights[j*8+6]; lstore[j].m_blue=lights[j*8+7];
+  lptrs[j]=&lstore[j];
+ }
+ b.m_log_render_size=log_render_size;
+ b.m_colour=colour;
+ b.m_log_texture_space_size=log_texture_space_size;
+ b.m_texture=(tex>=0)?&g_textures[tex]:NULL;
+ for(int i=0;i<16*T_LNG_VECTOR;i++) b.m_controls[i]=controls[i];
+ b.m_normals=NULL; b.m_intensities=NULL;
+ M_init_bicubic(&b);
+ for(int i=0;i<size*size*T_LNG_VECTOR;i++) normals[i]=b.m_normals[i];
+ M_shade_bicubic(&b,x,y,z,alp,bet,gam,nl,lptrs.data());
+ for(int i=0;i<size*size*3;i++) intensities[i]=b.m_intensities[i];
+ M_init_rendering(type);
+ M_set_camera(0,0,0,0,0,0,log_focus);
+ M_force_linear_tmapping=force_linear;
+ M_render_bicubic(&b,x,y,z,alp,bet,gam);
+ M_force_linear_tmapping=old;
+ free(b.m_normals); free(b.m_intensities);
+}
+
 /* The real G_line (GraphicsBase.cpp:165-253); v1, v2 = projected {X, Y, Z} */
 void ltref_g_line(int *v1,int *v2,int colour,int r,int g,int b)
 {

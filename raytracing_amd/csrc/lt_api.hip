@@ -804,6 +804,47 @@ int lt_shade_object(lt_ctx *c, const int32_t s9[9], int32_t x, int32_t y, int32_
     return LT_OK;
 }
 
+int lt_shade_points_dev(lt_ctx *c, const int32_t s9[9], const int32_t *d_points, const int32_t *d_normals, int n,
+                        const lt_light *lights, int nlights, int32_t *d_rgb)
+{
+    if (!c) return LT_ERR_ARG;
+    if (n < 0 || nlights < 0) return fail(c, LT_ERR_ARG, "lt_shade_points: negative count");
+    if (nlights > LT_MAX_LIGHTS) return fail(c, LT_ERR_ARG, "lt_shade_points: %d lights, at most %d", nlights, LT_MAX_LIGHTS);
+    if (n == 0) return LT_OK;
+    if (!s9 || !d_points || !d_normals || !d_rgb || (nlights && !lights)) return fail(c, LT_ERR_ARG, "lt_shade_points: NULL array");
+    int rc = use_device(c);
+    if (rc) return rc;
+    ShadeArgs a{};
+    for (int i = 0; i < 9; i++) a.s[i] = s9[i];
+    a.nlights = nlights;
+    for (int j = 0; j < nlights; j++) memcpy(a.lights[j], &lights[j], sizeof(lt_light));
+    a.status = c->status;
+    launch_shade_points(c->stream, a, d_points, d_normals, n, d_rgb);
+    HIPCHK(c, hipGetLastError());
+    return LT_OK;
+}
+
+int lt_shade_points(lt_ctx *c, const int32_t s9[9], const int32_t *points, const int32_t *normals, int n,
+                    const lt_light *lights, int nlights, int32_t *rgb)
+{
+    if (!c) return LT_ERR_ARG;
+    if (n == 0) return LT_OK;
+    if (n < 0 || !points || !normals || !rgb) return fail(c, LT_ERR_ARG, "lt_shade_points: bad argument");
+    int rc = lt_flush(c);
+    if (rc) return rc;
+    if ((rc = ensure(c, c->s_verts, (size_t)n * 16))) return rc;
+    if ((rc = ensure(c, c->s_normals, (size_t)n * 16))) return rc;
+    if ((rc = ensure(c, c->s_aux, (size_t)n * 16))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_verts.p, points, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_normals.p, normals, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    if ((rc = lt_shade_points_dev(c, s9, (const int32_t *)c->s_verts.p, (const int32_t *)c->s_normals.p, n, lights, nlights,
+                                  (int32_t *)c->s_aux.p)))
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(rgb, c->s_aux.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return lt_flush(c);                            // reports a point light at a point
+}
+
 int lt_plane_normals_dev(lt_ctx *c, const int32_t *d_verts, int nv, const int32_t *d_polys, int np,
                          const int32_t *d_polyverts, int npv, int32_t *d_plane_normals)
 {

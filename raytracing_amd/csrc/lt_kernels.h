@@ -138,6 +138,7 @@ void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0,
 void launch_plane_normals(hipStream_t s, const int *verts, int nv, const int *polys, int np, const int *polyverts,
                           int npv, int *out, Status *status);
 void launch_shade(hipStream_t s, const ShadeArgs &a);
+void launch_shade_points(hipStream_t s, const ShadeArgs &a, const int *points, const int *normals, int n, int *rgb);
 
 void launch_transform(hipStream_t s, const int *m12_dev, const int *from, int *to, int n);
 void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);

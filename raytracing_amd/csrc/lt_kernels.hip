@@ -205,6 +205,61 @@ __global__ void __launch_bounds__(256) plane_normals_kernel(const int *__restric
         atomicAdd(&status[blockIdx.x % STATUS_SLOTS].zero_light_vectors, (unsigned long long)__popcll(m));
 }
 
+// M_shade_vertex, EngBase.cpp:220-288 (_RGB_): light from the list at a world-space point
+// with a world-space normal.  `zero` counts point lights at zero distance (left out; the
+// reference stops in T_unit_vector there).
+__device__ __forceinline__ void shade_vertex(const ShadeArgs &a, const int (&wv)[3], const int (&wn)[3], int (&rgb)[3],
+                                             unsigned &zero)
+{
+    rgb[0] = 0; rgb[1] = 0; rgb[2] = 0;
+    for (int j = 0; j < a.nlights; j++) {
+        const int type = a.lights[j][0];
+        const int lc[3] = {a.lights[j][5], a.lights[j][6], a.lights[j][7]};
+        const int lp[3] = {a.lights[j][1], a.lights[j][2], a.lights[j][3]};
+        int prd = -1;
+        if (type == 1) {                                   // M_AMBIENT
+#pragma unroll
+            for (int q = 0; q < 3; q++) rgb[q] = wadd(rgb[q], lc[q]);
+        } else if (type == 2) {                            // M_POINT: T_unit_vector, TransLn.cpp:175-190
+            const int v[3] = {wsub(lp[0], wv[0]), wsub(lp[1], wv[1]), wsub(lp[2], wv[2])};
+            const long long lng = t_norm(v);
+            if (lng == 0) zero++;
+            else {
+                const int lv[3] = {unit_component(v[0], lng), unit_component(v[1], lng), unit_component(v[2], lng)};
+                prd = scalar_product(lv, wn);
+            }
+        } else if (type == 4) {                            // M_DIRECT
+            prd = (int)(0u - (unsigned)scalar_product(lp, wn));
+        }
+        if (type != 1 && prd >= 0) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) rgb[q] = wadd(rgb[q], wmul(prd, lc[q]) >> 7);
+        }
+    }
+}
+
+// The shading loop of M_shade_bicubic (EngBcub.cpp:314-325): n points already in world space,
+// their normals rotated by the self rotation here (T_self_rotation, EngBcub.cpp:291);
+// rgb[i] = {R, G, B, 0}.  One point per lane.
+__global__ void __launch_bounds__(256) shade_points_kernel(ShadeArgs a, const int4 *__restrict__ points,
+                                                           const int4 *__restrict__ normals, int n, int4 *__restrict__ rgb_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned zero = 0;
+    if (i < n) {
+        const int4 p = points[i];
+        const int wv[3] = {p.x, p.y, p.z};
+        int wn[3], rgb[3];
+        self_rotate(a.s, normals[i], wn);
+        shade_vertex(a, wv, wn, rgb, zero);
+        rgb_out[i] = make_int4(rgb[0], rgb[1], rgb[2], 0);
+    }
+    unsigned long long zs = zero;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) zs += __shfl_down(zs, d);
+    if ((threadIdx.x & 63) == 0 && zs) atomicAdd(&a.status[blockIdx.x % STATUS_SLOTS].zero_light_vectors, zs);
+}
+
 // M_shade_polygon over M_shade_vertex (EngBase.cpp:220-364): one polygon per lane; every
 // record of the polygon gets its R,G,B from the light list, the polygon its flat
 // illumination (the truncated mean over its n_edges+1 records).  Vertices and normals are
@@ -254,31 +309,8 @@ __global__ void __launch_bounds__(256) shade_kernel(ShadeArgs a)
                     self_rotate(a.s, pv[g], wv);
                     wv[0] = wadd(wv[0], a.x); wv[1] = wadd(wv[1], a.y); wv[2] = wadd(wv[2], a.z);
                     self_rotate(a.s, pn[g], wn);
-                    int rgb[3] = {0, 0, 0};
-                    for (int j = 0; j < a.nlights; j++) {
-                        const int type = a.lights[j][0];
-                        const int lc[3] = {a.lights[j][5], a.lights[j][6], a.lights[j][7]};
-                        const int lp[3] = {a.lights[j][1], a.lights[j][2], a.lights[j][3]};
-                        int prd = -1;
-                        if (type == 1) {                                   // M_AMBIENT
-#pragma unroll
-                            for (int q = 0; q < 3; q++) rgb[q] = wadd(rgb[q], lc[q]);
-                        } else if (type == 2) {                            // M_POINT: T_unit_vector, TransLn.cpp:175-190
-                            const int v[3] = {wsub(lp[0], wv[0]), wsub(lp[1], wv[1]), wsub(lp[2], wv[2])};
-                            const long long lng = t_norm(v);
-                            if (lng == 0) zero++;
-                            else {
-                                const int lv[3] = {unit_component(v[0], lng), unit_component(v[1], lng), unit_component(v[2], lng)};
-                                prd = scalar_product(lv, wn);
-                            }
-                        } else if (type == 4) {                            // M_DIRECT
-                            prd = (int)(0u - (unsigned)scalar_product(lp, wn));
-                        }
-                        if (type != 1 && prd >= 0) {
-#pragma unroll
-                            for (int q = 0; q < 3; q++) rgb[q] = wadd(rgb[q], wmul(prd, lc[q]) >> 7);
-                        }
-                    }
+                    int rgb[3];
+                    shade_vertex(a, wv, wn, rgb, zero);
                     rec[0] = make_int2(ra[g].x, rgb[0]);
                     rec[1] = make_int2(rgb[1], rgb[2]);
                     rec[2] = rc[g];
@@ -1990,6 +2022,13 @@ void launch_transform(hipStream_t s, const int *m12, const int *from, int *to, i
     Mat12 M;
     for (int i = 0; i < 12; i++) M.m[i] = m12[i];
     hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, M, (const int4 *)from, to, n);
+}
+
+void launch_shade_points(hipStream_t s, const ShadeArgs &a, const int *points, const int *normals, int n, int *rgb)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(shade_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, (const int4 *)points, (const int4 *)normals,
+                       n, (int4 *)rgb);
 }
 
 void launch_shade(hipStream_t s, const ShadeArgs &a)

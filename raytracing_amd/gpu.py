@@ -162,6 +162,15 @@ class Context:
                                          _p(li), li.shape[0]))
         return pv, pa
 
+    def shade_points(self, s9, points, normals, lights):
+        """M_shade_vertex for world-space points int32[n][4] with normals int32[n][4] (rotated by
+        s9 on the device) -> int32[n][3]"""
+        s, li = _i32(s9), _i32(lights).reshape(-1, 8)
+        p, n = _i32(points).reshape(-1, 4), _i32(normals).reshape(-1, 4)
+        out = np.zeros((p.shape[0], 4), np.int32)
+        self._chk(self.L.lt_shade_points(self.h_ctx, _p(s), _p(p), _p(n), p.shape[0], _p(li), li.shape[0], _p(out)))
+        return out[:, :3].copy()
+
     def set_clip_window(self, minx, miny, maxx, maxy):
         """C_init_clipping for the batches submitted next"""
         self._chk(self.L.lt_set_clip_window(self.h_ctx, int(minx), int(miny), int(maxx), int(maxy)))

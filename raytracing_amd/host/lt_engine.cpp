@@ -464,7 +464,6 @@ static int lt_type()
 void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *textures)
 {
     need_ctx();
-    if (colours || textures) HW_error((char *)"(Engine) per-vertex colour/texture arrays are not supported by the GPU path.\n");
     const int type = lt_type();
     open_queue(Q_VIEW, type);
     const int base = (int)(q_verts.size() / 4);
@@ -476,11 +475,230 @@ void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *
         const int32_t vv[4] = {v[0], v[1], v[2], 0};
         q_verts.insert(q_verts.end(), vv, vv + 4);
         memcpy(&recs[(size_t)k * 6], r, sizeof(int) * 6);
+        // CI_construct_tuples, EngBase.cpp:106-131: with the optional arrays R,G,B and Tx,Ty come
+        // from them, indexed like the vertices, and the record's own fields are skipped
+        if (colours) for (int q = 0; q < 3; q++) recs[(size_t)k * 6 + 1 + q] = colours[(size_t)r[0] * 3 + q];
+        if (textures) for (int q = 0; q < 2; q++) recs[(size_t)k * 6 + 4 + q] = textures[(size_t)r[0] * 2 + q];
         recs[(size_t)k * 6] = k;
     }
     tmp.m_vertices = recs.data();
     flatten_polygon(&tmp, base, q_polys, q_aux, q_pv);
     if (poly->m_no_edges > q_max_edges) q_max_edges = poly->m_no_edges;
+}
+
+// ------------------------------------------------------------------ bicubic patches (EngBcub.cpp)
+//
+// Tessellation is host work here as in the reference (at most 33 x 33 points a patch, halving
+// integer control polygons); normals and shading run on the GPU (lt_plane_normals,
+// lt_shade_points) and every square is drawn through M_render_polygon, i.e. the GPU queue.
+
+namespace {
+
+inline int half_sum(int a, int b) { return wadd(a, b) / 2; }       // (a + b) / 2 of the reference: truncating
+
+// Points of the cubic Bezier curve with controls b1..b4 at `length` = 2^k + 1 equally spaced
+// parameters, `stride` ints apart (EngBcub.cpp:113-152): the ends are the outer controls, the
+// middle comes from three rounds of halving, and each half is a curve again.
+void curve_points(const int *b1, const int *b2, const int *b3, const int *b4, int *points, int stride, int length, bool top)
+{
+    if (top) {
+        memcpy(points, b1, sizeof(int) * 3);
+        memcpy(points + (size_t)(length - 1) * stride, b4, sizeof(int) * 3);
+    }
+    if (length <= 2) return;
+    int b12[3], b23[3], b34[3], b123[3], b234[3];
+    int *mid = points + (size_t)(length / 2) * stride;
+    for (int k = 0; k < 3; k++) {
+        b12[k] = half_sum(b1[k], b2[k]); b23[k] = half_sum(b2[k], b3[k]); b34[k] = half_sum(b3[k], b4[k]);
+        b123[k] = half_sum(b12[k], b23[k]); b234[k] = half_sum(b23[k], b34[k]);
+        mid[k] = half_sum(b123[k], b234[k]);
+    }
+    curve_points(b1, b12, b123, mid, points, stride, length / 2 + 1, false);
+    curve_points(mid, b234, b34, b4, mid, stride, length / 2 + 1, false);
+}
+
+// Tangents at the same parameters (EngBcub.cpp:163-196): differences of neighbouring controls of
+// the halved polygons.
+void curve_tangents(const int *b1, const int *b2, const int *b3, const int *b4, int *tangents, int stride, int length, bool top)
+{
+    if (top)
+        for (int k = 0; k < 3; k++) {
+            tangents[k] = (int)((unsigned)b2[k] - (unsigned)b1[k]);
+            tangents[(size_t)(length - 1) * stride + k] = (int)((unsigned)b4[k] - (unsigned)b3[k]);
+        }
+    if (length <= 2) return;
+    int b12[3], b23[3], b34[3], b123[3], b234[3], b1234[3];
+    int *mid = tangents + (size_t)(length / 2) * stride;
+    for (int k = 0; k < 3; k++) {
+        b12[k] = half_sum(b1[k], b2[k]); b23[k] = half_sum(b2[k], b3[k]); b34[k] = half_sum(b3[k], b4[k]);
+        b123[k] = half_sum(b12[k], b23[k]); b234[k] = half_sum(b23[k], b34[k]);
+        mid[k] = (int)((unsigned)b234[k] - (unsigned)b123[k]);
+        b1234[k] = half_sum(b123[k], b234[k]);
+    }
+    curve_tangents(b1, b12, b123, b1234, tangents, stride, length / 2 + 1, false);
+    curve_tangents(b1234, b234, b34, b4, mid, stride, length / 2 + 1, false);
+}
+
+// size x size points of a patch: four curves along one parameter through controls
+// (k, k+4, k+8, k+12), then one curve per position along the other
+void patch_points(const int *c, int *points, int size)
+{
+    std::vector<int> t((size_t)4 * size * T_LNG_VECTOR, 0);
+    for (int k = 0; k < 4; k++)
+        curve_points(c + k * T_LNG_VECTOR, c + (k + 4) * T_LNG_VECTOR, c + (k + 8) * T_LNG_VECTOR, c + (k + 12) * T_LNG_VECTOR,
+                     &t[(size_t)k * size * T_LNG_VECTOR], T_LNG_VECTOR, size, true);
+    for (int i = 0; i < size; i++)
+        curve_points(&t[(size_t)i * T_LNG_VECTOR], &t[(size_t)(size + i) * T_LNG_VECTOR], &t[(size_t)(2 * size + i) * T_LNG_VECTOR],
+                     &t[(size_t)(3 * size + i) * T_LNG_VECTOR], points + (size_t)i * size * T_LNG_VECTOR, T_LNG_VECTOR, size, true);
+}
+
+int patch_size(const M_bicubic *b, bool init)
+{
+    const int size = (1 << b->m_log_render_size) + 1;
+    if (b->m_log_render_size < 0 || (init ? size >= M_MAX_RENDER_SIZE : size > M_MAX_RENDER_SIZE))
+        HW_error((char *)"(Engine) Can't subdivide a bicubic this much.\n");       // EngBcub.cpp:215-216, 287-288
+    return size;
+}
+
+int M_square_v[30] = {2, 0, 0, 0, 0, 0,  3, 0, 0, 0, 0, 0,  1, 0, 0, 0, 0, 0,  0, 0, 0, 0, 0, 0,  2, 0, 0, 0, 0, 0};
+M_polygon M_square = {M_QUAD_XY, 0, 0, 0, 0, 0, nullptr, 4, M_square_v, nullptr};   // EngBcub.cpp:49-60
+
+}  // namespace
+
+// EngBcub.cpp:204-265: the normal at every point of the tessellation = vector product of the
+// tangents along the two parameters (T_normal_vectors, i.e. T_normal_plane from the origin:
+// computed by lt_plane_normals).  A zero-length product stops the reference and this.
+void M_init_bicubic(struct M_bicubic *bicubic)
+{
+    need_ctx();
+    const int size = patch_size(bicubic, true), n = size * size;
+    const int *c = bicubic->m_controls;
+    bicubic->m_normals = (int *)malloc(sizeof(int) * T_LNG_VECTOR * n);
+    bicubic->m_intensities = (int *)malloc(sizeof(int) * 3 * n);
+    if (!bicubic->m_normals || !bicubic->m_intensities) HW_error((char *)"(Engine) Not enough memory.\n");
+    // vertex 0 is the origin, then the two tangent fields
+    std::vector<int32_t> v((size_t)(1 + 2 * n) * 4, 0), t((size_t)4 * size * T_LNG_VECTOR, 0);
+    int *tan1 = &v[4], *tan2 = &v[(size_t)(1 + n) * 4];
+    for (int k = 0; k < 4; k++)
+        curve_points(c + 4 * k * T_LNG_VECTOR, c + (4 * k + 1) * T_LNG_VECTOR, c + (4 * k + 2) * T_LNG_VECTOR,
+                     c + (4 * k + 3) * T_LNG_VECTOR, &t[(size_t)k * size * T_LNG_VECTOR], T_LNG_VECTOR, size, true);
+    for (int i = 0; i < size; i++)
+        curve_tangents(&t[(size_t)i * T_LNG_VECTOR], &t[(size_t)(size + i) * T_LNG_VECTOR], &t[(size_t)(2 * size + i) * T_LNG_VECTOR],
+                       &t[(size_t)(3 * size + i) * T_LNG_VECTOR], tan1 + i * T_LNG_VECTOR, T_LNG_VECTOR * size, size, true);
+    for (int k = 0; k < 4; k++)
+        curve_points(c + k * T_LNG_VECTOR, c + (k + 4) * T_LNG_VECTOR, c + (k + 8) * T_LNG_VECTOR, c + (k + 12) * T_LNG_VECTOR,
+                     &t[(size_t)k * size * T_LNG_VECTOR], T_LNG_VECTOR, size, true);
+    for (int i = 0; i < size; i++)
+        curve_tangents(&t[(size_t)i * T_LNG_VECTOR], &t[(size_t)(size + i) * T_LNG_VECTOR], &t[(size_t)(2 * size + i) * T_LNG_VECTOR],
+                       &t[(size_t)(3 * size + i) * T_LNG_VECTOR], tan2 + (size_t)i * size * T_LNG_VECTOR, T_LNG_VECTOR, size, true);
+    std::vector<int32_t> polys((size_t)n * 4), pv((size_t)n * 3 * 6, 0), out((size_t)n * 4);
+    for (int i = 0; i < n; i++) {
+        polys[(size_t)i * 4] = 0; polys[(size_t)i * 4 + 1] = -1; polys[(size_t)i * 4 + 2] = 2; polys[(size_t)i * 4 + 3] = 3 * i;
+        pv[(size_t)(3 * i) * 6] = 0; pv[(size_t)(3 * i + 1) * 6] = 1 + i; pv[(size_t)(3 * i + 2) * 6] = 1 + n + i;
+    }
+    chk(lt_plane_normals(g_ctx, v.data(), 1 + 2 * n, polys.data(), n, pv.data(), 3 * n, out.data()));
+    memcpy(bicubic->m_normals, out.data(), sizeof(int) * 4 * n);
+}
+
+// EngBcub.cpp:271-326: controls to world space, points from them, M_shade_vertex at every point
+// with its rotated normal (lt_shade_points)
+void M_shade_bicubic(struct M_bicubic *bicubic, int x, int y, int z, int alp, int bet, int gam, int no_lights,
+                     struct M_light **lights)
+{
+    need_ctx();
+    const int size = patch_size(bicubic, false), n = size * size;
+    if (no_lights > LT_MAX_LIGHTS) HW_error((char *)"(Engine) more lights than the GPU path takes.\n");
+    T_set_self_rotation((unsigned char)alp, (unsigned char)bet, (unsigned char)gam);
+    int c[16 * T_LNG_VECTOR];
+    for (int i = 0; i < 16; i++) {
+        const int *p = bicubic->m_controls + i * T_LNG_VECTOR;
+        for (int r = 0; r < 3; r++)
+            c[i * T_LNG_VECTOR + r] = wadd(wadd(fx(Ts[3 * r], p[0]), fx(Ts[3 * r + 1], p[1])), fx(Ts[3 * r + 2], p[2]));
+        c[i * T_LNG_VECTOR] = wadd(c[i * T_LNG_VECTOR], x);
+        c[i * T_LNG_VECTOR + 1] = wadd(c[i * T_LNG_VECTOR + 1], y);
+        c[i * T_LNG_VECTOR + 2] = wadd(c[i * T_LNG_VECTOR + 2], z);
+        c[i * T_LNG_VECTOR + 3] = 0;
+    }
+    std::vector<int32_t> points((size_t)n * 4, 0), rgb((size_t)n * 4, 0);
+    patch_points(c, points.data(), size);
+    std::vector<lt_light> ls((size_t)(no_lights > 0 ? no_lights : 0));
+    for (int j = 0; j < no_lights; j++) {
+        ls[j].type = lights[j]->m_type;
+        for (int k = 0; k < 4; k++) ls[j].param[k] = lights[j]->m_parameter[k];
+        ls[j].red = lights[j]->m_red; ls[j].green = lights[j]->m_green; ls[j].blue = lights[j]->m_blue;
+    }
+    chk(lt_shade_points(g_ctx, Ts, points.data(), bicubic->m_normals, n, ls.data(), no_lights, rgb.data()));
+    for (int i = 0; i < n; i++)
+        for (int q = 0; q < 3; q++) bicubic->m_intensities[i * 3 + q] = rgb[(size_t)i * 4 + q];
+}
+
+// EngBcub.cpp:332-403 with a depth buffer (no sorting): controls to view space with M_PB more
+// fraction bits, points, a grid of texture coordinates, then every square as a four-edge
+// polygon through M_render_polygon (MI_render_square, :68-102)
+void M_render_bicubic(struct M_bicubic *bicubic, int x, int y, int z, int alp, int bet, int gam)
+{
+    need_ctx();
+    const int size = patch_size(bicubic, false), n = size * size;
+    T_set_self_rotation((unsigned char)alp, (unsigned char)bet, (unsigned char)gam);
+    T_cancatinate_self_world(x + M_camera_x, y + M_camera_y, z + M_camera_z);
+    int c[16 * T_LNG_VECTOR] = {0};
+    T_cancatinated_rotation(bicubic->m_controls, c, 16);
+    int incr = bicubic->m_log_texture_space_size - bicubic->m_log_render_size;
+    if (incr <= 0) HW_error((char *)"(Engine) Too small a texture to fit onto a bicubic.\n");
+    M_square.m_colour = bicubic->m_colour;
+    M_square.m_log_texture_space_size = incr;
+    M_square.m_texture = bicubic->m_texture;
+    incr = 1 << incr;
+    const int max = 1 << bicubic->m_log_texture_space_size;
+    std::vector<int> points((size_t)n * T_LNG_VECTOR, 0), textures((size_t)n * 2);
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) { textures[(size_t)(i * size + j) * 2] = j * incr; textures[(size_t)(i * size + j) * 2 + 1] = max - i * incr; }
+    for (int i = 0; i < 16; i++)
+        for (int q = 0; q < 3; q++) c[i * T_LNG_VECTOR + q] = (int)((unsigned)c[i * T_LNG_VECTOR + q] << M_PB);
+    patch_points(c, points.data(), size);
+    for (int i = 0; i < n; i++) {
+        if (i % size == size - 1 || i / size == size - 1) continue;
+        const int no[4] = {i, i + 1, i + size, i + size + 1};
+        int vert[4 * T_LNG_VECTOR], colr[4 * 3], tex[4 * 2];
+        for (int k = 0; k < 4; k++) {
+            for (int q = 0; q < 3; q++) vert[k * T_LNG_VECTOR + q] = points[(size_t)no[k] * T_LNG_VECTOR + q] >> M_PB;
+            vert[k * T_LNG_VECTOR + 3] = 0;
+            for (int q = 0; q < 3; q++) colr[k * 3 + q] = bicubic->m_intensities[no[k] * 3 + q];
+            tex[k * 2] = textures[(size_t)no[k] * 2]; tex[k * 2 + 1] = textures[(size_t)no[k] * 2 + 1];
+        }
+        M_square.m_red = colr[0]; M_square.m_green = colr[1]; M_square.m_blue = colr[2];
+        M_render_polygon(&M_square, vert, colr, tex);
+    }
+}
+
+// EngBcub.cpp:410-488
+void M_init_bicubic_object(struct M_bicubic_object *object)
+{
+    object->m_centres = (int *)malloc(sizeof(int) * T_LNG_VECTOR * (object->m_no_patches > 0 ? object->m_no_patches : 1));
+    if (!object->m_centres) HW_error((char *)"(Engine) Not enough memory.\n");
+    for (int i = 0; i < object->m_no_patches; i++) {
+        M_init_bicubic(object->m_patches[i]);
+        for (int q = 0; q < 3; q++) {
+            int sum = 0;
+            for (int j = 0; j < 16; j++) sum = wadd(sum, object->m_patches[i]->m_controls[j * T_LNG_VECTOR + q]);
+            object->m_centres[i * T_LNG_VECTOR + q] = sum / 16;
+        }
+    }
+}
+
+void M_shade_bicubic_object(struct M_bicubic_object *object, int x, int y, int z, int alp, int bet, int gam, int no_lights,
+                            struct M_light **lights)
+{
+    for (int i = 0; i < object->m_no_patches; i++) M_shade_bicubic(object->m_patches[i], x, y, z, alp, bet, gam, no_lights, lights);
+}
+
+void M_render_bicubic_object(struct M_bicubic_object *object, int x, int y, int z, int alp, int bet, int gam)
+{
+    if (object->m_no_patches > M_MAX_PATCHES) HW_error((char *)"(Engine) Too many bicubic patches per object.\n");
+    const int old = M_force_linear_tmapping;
+    M_force_linear_tmapping = 1;                     // EngBcub.cpp:469-470: the squares are small enough
+    for (int i = 0; i < object->m_no_patches; i++) M_render_bicubic(object->m_patches[i], x, y, z, alp, bet, gam);
+    M_force_linear_tmapping = old;
 }
 
 // EngBase.cpp:567-629: the clip window becomes its intersection with the screen extent of a

@@ -148,6 +148,34 @@ void M_init_polygon_object(struct M_polygon_object *object);
 void M_shade_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam,
                             int no_lights, struct M_light **lights);
 
+// Engine.h:78, 275-300, 490-516 and EngBcub.cpp: bicubic Bezier patches, tessellated into squares
+#define M_PB 8
+#define M_MAX_RENDER_SIZE 33
+#define M_MAX_PATCHES 128
+struct M_bicubic {
+    int m_log_render_size;
+    HW_pixel m_colour;
+    int m_log_texture_space_size;
+    struct M_texture *m_texture;
+    int m_controls[16 * T_LNG_VECTOR];
+    int *m_normals;
+    int *m_intensities;
+};
+struct M_bicubic_object {
+    int m_type;
+    int m_no_patches;
+    struct M_bicubic **m_patches;
+    int *m_centres;
+};
+void M_init_bicubic(struct M_bicubic *bicubic);
+void M_shade_bicubic(struct M_bicubic *bicubic, int x, int y, int z, int alp, int bet, int gam, int no_lights,
+                     struct M_light **lights);
+void M_render_bicubic(struct M_bicubic *bicubic, int x, int y, int z, int alp, int bet, int gam);
+void M_init_bicubic_object(struct M_bicubic_object *object);
+void M_shade_bicubic_object(struct M_bicubic_object *object, int x, int y, int z, int alp, int bet, int gam, int no_lights,
+                            struct M_light **lights);
+void M_render_bicubic_object(struct M_bicubic_object *object, int x, int y, int z, int alp, int bet, int gam);
+
 void M_init_rendering(int type);
 void M_set_camera(unsigned char alp, unsigned char bet, unsigned char gam, int x, int y, int z, int log_focus);
 void M_render_polygon(struct M_polygon *polygon, int *vertices, int *colours, int *textures);

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <vector>
 
+static M_texture g_texs[64];        // textures registered through lte_set_texture
+
 extern "C" {
 
 void lte_init(int w, int h)
@@ -23,6 +25,48 @@ void lte_flush(void) { HW_flush(); }
 int lte_cl_light(int c, int r, int g, int b) { return CL_light(c, r, g, b); }
 void lte_init_clipping(int minx, int miny, int maxx, int maxy) { C_init_clipping(minx, miny, maxx, maxy); }
 int lte_set_bounds(int minx, int miny, int maxx, int maxy) { return C_set_bounds(minx, miny, maxx, maxy); }
+// M_init_bicubic + M_shade_bicubic + M_render_bicubic (through a one-patch M_bicubic_object when
+// as_object) of one patch into the current frame; normals[size*size][4], intensities[size*size][3]
+void lte_bicubic(const int *controls, int log_render_size, int colour, int log_texture_space_size, int tex, int x, int y, int z,
+                 int alp, int bet, int gam, const int *lights, int nl, int type, int log_focus, int as_object, int *normals,
+                 int *intensities)
+{
+    M_bicubic b;
+    M_bicubic *bp = &b;
+    const int size = (1 << log_render_size) + 1;
+    std::vector<M_light> ls(nl);
+    std::vector<M_light *> lp(nl);
+    for (int j = 0; j < nl; j++) {
+        ls[j].m_type = lights[j * 8];
+        for (int k = 0; k < 4; k++) ls[j].m_parameter[k] = lights[j * 8 + 1 + k];
+        ls[j].m_red = lights[j * 8 + 5]; ls[j].m_green = lights[j * 8 + 6]; ls[j].m_blue = lights[j * 8 + 7];
+        lp[j] = &ls[j];
+    }
+    b.m_log_render_size = log_render_size;
+    b.m_colour = colour;
+    b.m_log_texture_space_size = log_texture_space_size;
+    b.m_texture = tex >= 0 ? &g_texs[tex] : nullptr;
+    for (int i = 0; i < 64; i++) b.m_controls[i] = controls[i];
+    b.m_normals = nullptr; b.m_intensities = nullptr;
+    M_init_rendering(type);
+    M_set_camera(0, 0, 0, 0, 0, 0, log_focus);
+    if (as_object) {
+        M_bicubic_object o;
+        o.m_type = M_POLYGON_OBJECT; o.m_no_patches = 1; o.m_patches = &bp; o.m_centres = nullptr;
+        M_init_bicubic_object(&o);
+        M_shade_bicubic_object(&o, x, y, z, alp, bet, gam, nl, lp.data());
+        M_render_bicubic_object(&o, x, y, z, alp, bet, gam);
+        free(o.m_centres);
+    } else {
+        M_init_bicubic(&b);
+        M_shade_bicubic(&b, x, y, z, alp, bet, gam, nl, lp.data());
+        M_render_bicubic(&b, x, y, z, alp, bet, gam);
+    }
+    for (int i = 0; i < size * size * 4; i++) normals[i] = b.m_normals[i];
+    for (int i = 0; i < size * size * 3; i++) intensities[i] = b.m_intensities[i];
+    free(b.m_normals); free(b.m_intensities);
+}
+
 // host-only use (no GPU context): screen size and full-screen window for the clippers and T_perspective
 void lte_screen_size(int w, int h) { HW_init_screen_size(w, h); C_init_clipping(0, 0, w - 1, h - 1); }
 int lte_set_gate(int no_edges, int *indices, int *vertices, int log_focus)
@@ -52,7 +96,6 @@ static void fill(M_polygon *p, M_texture *texs, const int *polys, const int *aux
     p->m_normals = nullptr;
 }
 
-static M_texture g_texs[64];
 void lte_set_texture(int handle, int *texels, int log_size)
 {
     g_texs[handle].m_texture_bytes = texels;

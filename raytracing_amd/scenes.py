@@ -384,3 +384,16 @@ def gen_sphere_object(n_long: int = 16, n_lat: int = 8, radius: int = 300, centr
             recs.append((idx, 0, 0, 0, 0, 0))
     return dict(verts=verts, polys=np.array(polys, np.int32), types=np.array(types, np.int32),
                 polyverts=np.array(recs, np.int32))
+
+
+def gen_bicubic_patch(seed: int, extent: int = 300, bulge: int = 150, centre=(0, 0, 900)):
+    """16 control points int32[16][4] of a bicubic Bezier patch: a 4x4 grid in x, y around
+    `centre` with random displacements in all three coordinates."""
+    rng = Rng(seed)
+    c = np.zeros((16, 4), np.int32)
+    for i in range(4):
+        for j in range(4):
+            c[i * 4 + j, 0] = centre[0] + (j - 1.5) * 2 * extent / 3 + int(rng.ints(-bulge // 4, bulge // 4, 1)[0])
+            c[i * 4 + j, 1] = centre[1] + (i - 1.5) * 2 * extent / 3 + int(rng.ints(-bulge // 4, bulge // 4, 1)[0])
+            c[i * 4 + j, 2] = centre[2] + int(rng.ints(-bulge, bulge, 1)[0])
+    return c

@@ -420,6 +420,41 @@ def gate_kats():
     return dict(rc=np.array([a for a, _ in res], np.int32), bounds=np.array([b for _, b in res], np.int32))
 
 
+BICUBIC_LIGHTS = np.array([[1, 0, 0, 0, 0, 30, 30, 30], [2, 400, -500, -300, 0, 220, 200, 180],
+                           [4, 40, -90, 80, 0, 90, 100, 110]], np.int32)
+
+
+def bicubic_cases():
+    """(name, controls, log_render_size, render type, position, angles) of single patches drawn at
+    200x150 with log_focus 7, texture space 2^7, texture make_texture(9, 6) for M_TEXTURED"""
+    out = []
+    for seed in range(6):
+        c = S.gen_bicubic_patch(seed, extent=250 + 40 * seed, bulge=100 + 30 * seed, centre=(10 * seed, -20, 300 + 100 * seed))
+        rt = (S.M_FLAT, S.M_SHADED, S.M_TEXTURED, S.M_WIRE, S.M_SHADED, S.M_TEXTURED)[seed]
+        out.append((f"patch_{seed}", c, 2 + seed % 3, rt, (5, -3, 40 * seed), (seed * 7, 250 - seed * 3, seed)))
+    return out
+
+
+def run_bicubic_case(case, be):
+    """be: oracle.port.Oracle or oracle.ref.Ref of WIRE_W x WIRE_H -> (normals, intensities, colour, depth)"""
+    name, c, lrs, rt, pos, ang = case
+    be.set_texture(0, S.make_texture(9, 6), 6)
+    be.clear(0x000020, 255, 255, 255)
+    n, i = be.bicubic(c, lrs, 0xFFFFFF, 7, 0 if rt == S.M_TEXTURED else -1, pos, ang, BICUBIC_LIGHTS, rt, 7, 1)
+    return n[:, :3].copy(), i, be.cbuf().copy(), be.zbuf().copy()
+
+
+def bicubic_kats():
+    """Patches set up, shaded and drawn by the reference build: normals, intensities, frame digests."""
+    out = {}
+    for case in bicubic_cases():
+        n, i, c, z = run_bicubic_case(case, R.Ref(WIRE_W, WIRE_H))
+        out[case[0] + "_normals"] = n
+        out[case[0] + "_intensities"] = i
+        out[case[0] + "_digests"] = np.array([S.frame_digest(c), S.frame_digest(z)])
+    return out
+
+
 def window_cases():
     """Frames drawn under clip windows smaller than the screen (C_init_clipping): steps as in
     wire_cases plus ("window", (minx, miny, maxx, maxy)) and ("gpolys", kind, polygons of
@@ -514,6 +549,7 @@ def main():
     json.dump(wire_kats(), open(os.path.join(HERE, "wire_kats.json"), "w"), indent=1, sort_keys=True)
     json.dump(window_kats(), open(os.path.join(HERE, "window_kats.json"), "w"), indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "gate_kats.npz"), **gate_kats())
+    np.savez_compressed(os.path.join(HERE, "bicubic_kats.npz"), **bicubic_kats())
     if not os.path.isdir(REFDIR):
         raise SystemExit("needs /root/reference (run in the build container)")
     np.savez_compressed(os.path.join(HERE, "stage_kats.npz"), **stage_kats())
