@@ -212,7 +212,11 @@ int lt_shade_object(lt_ctx *ctx, const int32_t s9[9], int32_t x, int32_t y, int3
  * (Clipp2D.cpp:99-104, 132, 150): 0 in a program that draws only wireframes, a leftover of
  * the polygon clipper's calls after filled polygons.  This library uses 0.  Lines are
  * drawn after everything submitted before them and before everything submitted after.
- * The device array must be 16-byte aligned. */
+ * The eighth word selects the primitive: 0 a line; 1 G_dot (GraphicsBase.cpp:133-153) at
+ * (x1, y1) with depth z1: drawn if on the screen and nearer than the depth buffer; 2 G_pixel
+ * (:117-123) at (x1, y1): written without a depth test (off the screen it is dropped; the
+ * reference would write outside its buffer).  Neither looks at the clip window, as in the
+ * reference.  The device array must be 16-byte aligned. */
 int lt_submit_lines_dev(lt_ctx *ctx, const int32_t *d_lines, int n);
 int lt_submit_lines(lt_ctx *ctx, const int32_t *lines, int n);
 

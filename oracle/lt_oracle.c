@@ -747,6 +747,24 @@ void lto_g_line(lto_ctx *c,const i32 *vertex1,const i32 *vertex2,i32 colour,i32 
     }
 }
 
+/* G_dot, GraphicsBase.cpp:133-153 (_RGB_, _Z_BUFFER_) */
+void lto_g_dot(lto_ctx *c,const i32 *vertex,i32 colour,i32 r,i32 g,i32 b)
+{
+    if(vertex[0]>=0&&vertex[0]<c->w&&vertex[1]>=0&&vertex[1]<c->h)
+    {
+        size_t pos=(size_t)vertex[1]*c->w+vertex[0];
+        c->fragments++;
+        if(vertex[2]<c->zbuf[pos]) c->cbuf[pos]=lto_cl_light(colour,r,g,b);
+    }
+}
+
+/* G_pixel, GraphicsBase.cpp:117-123; the caller keeps the point on the screen */
+void lto_g_pixel(lto_ctx *c,const i32 *vertex,i32 colour)
+{
+    if(vertex[0]>=0&&vertex[0]<c->w&&vertex[1]>=0&&vertex[1]<c->h)
+        c->cbuf[(size_t)vertex[1]*c->w+vertex[0]]=colour;
+}
+
 /* M_render_polygon, EngBase.cpp:379-552, for one polygon of the flat scene layout.
  * polys[i] = {colour, texture handle or -1, no_edges, first};
  * polyaux[i] = {m_red, m_green, m_blue, m_type | log_texture_space_size<<8}. */

@@ -74,6 +74,10 @@ def lib():
                                          + [C.c_int] * 3)
         L.lto_set_clip_window.restype = None
         L.lto_set_clip_window.argtypes = [C.c_void_p] + [C.c_int32] * 4
+        L.lto_g_dot.restype = None
+        L.lto_g_dot.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 4
+        L.lto_g_pixel.restype = None
+        L.lto_g_pixel.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.lto_g_line.restype = None
         L.lto_g_line.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int32] * 4
         L.lto_normal_plane.restype = C.c_int
@@ -211,6 +215,14 @@ class Oracle:
                                      _p(inten), int(render_type), int(log_focus), int(force_linear)) != 0:
             raise ValueError("M_render_bicubic stops on this patch")
         return normals, inten
+
+    def g_dot(self, v, colour, r=0, g=0, b=0):
+        a = _i32(v)
+        self.L.lto_g_dot(self.c, _p(a), int(colour), int(r), int(g), int(b))
+
+    def g_pixel(self, v, colour):
+        a = _i32(v)
+        self.L.lto_g_pixel(self.c, _p(a), int(colour))
 
     def render_polys(self, viewverts, polys, polyaux, polyverts, render_type, log_focus, force_linear=0):
         vv, po, pv = _i32(viewverts), _i32(polys), _i32(polyverts)

@@ -224,3 +224,13 @@ class Ref:
                              int(render_type), int(log_focus), int(force_linear), _p(normals), _p(inten))
         return normals, inten
 
+    def g_dot(self, v, colour, r=0, g=0, b=0):
+        a = _i32(v).copy()
+        self.L.ltref_g_dot(_p(a), C.c_int(colour), int(r), int(g), int(b))
+
+    def g_pixel(self, v, colour):
+        """the real G_pixel: the point must be on the screen"""
+        a = _i32(v).copy()
+        assert 0 <= a[0] < self.w and 0 <= a[1] < self.h
+        self.L.ltref_g_pixel(_p(a), C.c_int(colour))
+

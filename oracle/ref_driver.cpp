@@ -291,6 +291,10 @@ void ltref_bicubic(const int *controls,int log_render_size,int colour,int log_te
  free(b.m_normals); free(b.m_intensities);
 }
 
+/* The real G_dot and G_pixel (GraphicsBase.cpp:117-153) */
+void ltref_g_dot(int *v,int colour,int r,int g,int b){ G_dot(v,colour,r,g,b); }
+void ltref_g_pixel(int *v,int colour){ G_pixel(v,colour); }
+
 /* The real G_line (GraphicsBase.cpp:165-253); v1, v2 = projected {X, Y, Z} */
 void ltref_g_line(int *v1,int *v2,int colour,int r,int g,int b)
 {

@@ -2301,8 +2301,9 @@ __global__ void __launch_bounds__(128) wire_kernel(SetupArgs a, const int *__res
     if (m && (threadIdx.x & 63) == (__ffsll((long long)m) - 1)) atomicAdd(&st->overflow_polys, (unsigned long long)__popcll(m));
 }
 
-// G_line for n lines in draw order: lines[i] = {x1, y1, z1, x2, y2, z2, lit colour, 0}
-__global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ lines, int n, int W, ClipWindow cw, int by0, int by1,
+// G_line for n lines in draw order: lines[i] = {x1, y1, z1, x2, y2, z2, lit colour, kind}; kind 1 and
+// 2 are G_dot and G_pixel at (x1, y1, z1)
+__global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ lines, int n, int W, int H, ClipWindow cw, int by0, int by1,
                                                     const int *__restrict__ zbuf, unsigned *winner, Status *status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2313,7 +2314,17 @@ __global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ line
         Tup<3> v1, v2;
         v1.v[0] = lo.x; v1.v[1] = lo.y; v1.v[2] = lo.z;
         v2.v[0] = lo.w; v2.v[1] = hi.x; v2.v[2] = hi.y;
-        draw_line(W, cw, by0, by1, zbuf, winner, v1, v2, (unsigned)i + 1u, tests, bad);
+        const int kind = hi.w;
+        if (kind == 0) {
+            draw_line(W, cw, by0, by1, zbuf, winner, v1, v2, (unsigned)i + 1u, tests, bad);
+        } else if ((unsigned)lo.x < (unsigned)W && (unsigned)lo.y < (unsigned)H && lo.y >= by0 && lo.y < by1) {
+            // G_dot (GraphicsBase.cpp:133-153): on the screen and nearer than the depth buffer;
+            // G_pixel (:117-123): no test at all (a pixel off the screen is dropped here, the
+            // reference would write outside its buffer)
+            const size_t pos = (size_t)lo.y * W + lo.x;
+            if (kind == 1) tests++;
+            if (kind == 2 || lo.z < zbuf[pos]) atomicMax(winner + pos, (unsigned)i + 1u);
+        }
     }
     Status *st = status + (blockIdx.x % STATUS_SLOTS);
     if (tests) atomicAdd(&st->fragments, tests);
@@ -2349,7 +2360,7 @@ void launch_lines(hipStream_t s, const int *lines, int n, int W, int H, int by0,
                   unsigned *winner, int *cbuf, Status *status)
 {
     if (n <= 0) return;
-    hipLaunchKernelGGL(lines_kernel, dim3((n + 127) / 128), dim3(128), 0, s, lines, n, W, cw, by0, by1, zbuf, winner, status);
+    hipLaunchKernelGGL(lines_kernel, dim3((n + 127) / 128), dim3(128), 0, s, lines, n, W, H, cw, by0, by1, zbuf, winner, status);
     const size_t np = (size_t)W * H;
     hipLaunchKernelGGL(line_resolve_kernel, dim3((unsigned)std::min<size_t>((np + 255) / 256, 8192)), dim3(256), 0, s, winner,
                        cbuf, np, lines, 0, 8, 6);

@@ -214,6 +214,23 @@ void G_line(int *vertex1, int *vertex2, HW_pixel colour, int red, int green, int
     q_lines.insert(q_lines.end(), l, l + 8);
 }
 
+// GraphicsBase.cpp:117-153: single points, queued with the lines (draw order is kept)
+void G_dot(int *vertex, HW_pixel colour, int red, int green, int blue)
+{
+    need_ctx();
+    open_queue(Q_LINES, 0);
+    const int32_t l[8] = {vertex[0], vertex[1], vertex[2], 0, 0, 0, CL_light(colour, red, green, blue), 1};
+    q_lines.insert(q_lines.end(), l, l + 8);
+}
+
+void G_pixel(int *vertex, HW_pixel colour)
+{
+    need_ctx();
+    open_queue(Q_LINES, 0);
+    const int32_t l[8] = {vertex[0], vertex[1], 0, 0, 0, 0, colour, 2};
+    q_lines.insert(q_lines.end(), l, l + 8);
+}
+
 void G_flat_polygon(int *edges, int length, HW_pixel colour, int red, int green, int blue)
 {
     queue_screen(LT_FLAT, G_LNG_FLAT, edges, length, CL_light(colour, red, green, blue), 0);

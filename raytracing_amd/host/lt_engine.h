@@ -45,6 +45,8 @@ extern int *G_z_buffer;
 extern long G_c_buffer_size;
 void G_init_graphics(void);
 void G_clear(HW_pixel colour, int red, int green, int blue);
+void G_pixel(int *vertex, HW_pixel colour);
+void G_dot(int *vertex, HW_pixel colour, int red, int green, int blue);
 void G_line(int *vertex1, int *vertex2, HW_pixel colour, int red, int green, int blue);
 void G_flat_polygon(int *edges, int length, HW_pixel colour, int red, int green, int blue);
 void G_shaded_polygon(int *edges, int length, HW_pixel colour);

@@ -82,6 +82,8 @@ int lte_polygon_clipping(int axis, int *from, int *to, int dim, int len)
     return axis == 0 ? C_polygon_x_clipping(from, to, dim, len) : C_polygon_z_clipping(from, to, dim, len);
 }
 void lte_perspective(int *from, int *to, int dim, int len, int log_focus) { T_perspective(from, to, dim, len, log_focus); }
+void lte_g_dot(int *v, int colour, int r, int g, int b) { G_dot(v, colour, r, g, b); }
+void lte_g_pixel(int *v, int colour) { G_pixel(v, colour); }
 void lte_g_line(int *v1, int *v2, int colour, int r, int g, int b) { G_line(v1, v2, colour, r, g, b); }
 
 static void fill(M_polygon *p, M_texture *texs, const int *polys, const int *aux, int *pv, int i)

@@ -388,6 +388,12 @@ def wire_cases():
          [WIRE_W - 1, 10, 0, WIRE_W - 1, 140, 0, 0x777777, 0], [-5, -5, 0, -1, -1, 0, 0x888888, 0],
          [WIRE_W, 3, 0, WIRE_W + 40, 100, 0, 0x999999, 0], [10, 0, 0, 150, 0, 0, 0xaaaaaa, 0],
          [10, WIRE_H - 1, 0, 150, WIRE_H - 1, 0, 0xbbbbbb, 0]], np.int32))]
+    pts = wire_lines(80, 600, -10, 10, -6200, -100)
+    pts[:, 7] = 1 + (np.arange(600) % 2)                        # G_dot and G_pixel in turn
+    pts[pts[:, 7] == 2, 0] = np.clip(pts[pts[:, 7] == 2, 0], 0, WIRE_W - 1)      # G_pixel is not bounds-checked
+    pts[pts[:, 7] == 2, 1] = np.clip(pts[pts[:, 7] == 2, 1], 0, WIRE_H - 1)
+    cases["dots_pixels"] = [("clear", 0), ("object", S.gen_c2(600, WIRE_W, WIRE_H, 7, radius=25, seed=8), S.M_SHADED, (0, 0, 0, 0, 0, 0)),
+                            ("lines", pts)]
     sc = S.gen_c2(800, WIRE_W, WIRE_H, 7, radius=20, seed=5)
     cases["mixed_unclipped"] = [("clear", 0), ("object", sc, S.M_SHADED, (0, 0, 0, 0, 0, 0)),
                                 ("lines", wire_lines(78, 300, 1, -2, -6200, -100)),
@@ -499,7 +505,12 @@ def _run_steps(steps, be):
             be.render_polys(P.transform(m, sc.verts), sc.polys, sc.polyaux, sc.polyverts, rt, sc.log_focus)
         else:
             for l in st[1]:
-                be.g_line(l[0:3], l[3:6], int(l[6]), 255, 255, 255)
+                if l[7] == 0:
+                    be.g_line(l[0:3], l[3:6], int(l[6]), 255, 255, 255)
+                elif l[7] == 1:
+                    be.g_dot(l[0:3], int(l[6]), 255, 255, 255)
+                else:
+                    be.g_pixel(l[0:3], int(l[6]))
     return be.cbuf().copy(), be.zbuf().copy()
 
 

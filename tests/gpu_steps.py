@@ -25,7 +25,7 @@ def run_gpu(P, ctx, steps, device_arrays=False):
                 ctx.submit_object(sc.verts, sc.polys, sc.polyverts, rt, sc.log_focus, polyaux=sc.polyaux, matrix=m)
         else:
             l = st[1].copy()
-            l[:, 6] = [P.cl_light(int(c), 255, 255, 255) for c in l[:, 6]]
+            l[:, 6] = [int(c) if k == 2 else P.cl_light(int(c), 255, 255, 255) for c, k in zip(l[:, 6], l[:, 7])]
             if device_arrays:
                 d = torch.from_numpy(l).cuda()
                 ctx.submit_lines_dev(d)

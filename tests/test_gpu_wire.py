@@ -118,6 +118,14 @@ def test_mirror_g_line_and_wire_object(env):
     for l in lines:
         a, b = np.ascontiguousarray(l[0:3]), np.ascontiguousarray(l[3:6])
         eng.lte_g_line(_p(a), _p(b), int(l[6]), 200, 100, 255)
+    for k, l in enumerate(MG.wire_lines(92, 200, -5, 5, -500, 500)):      # G_dot and G_pixel in turn, over the lines
+        a = np.ascontiguousarray(l[0:3])
+        if k % 2:
+            orc.g_dot(a, int(l[6]), 90, 255, 30)
+            eng.lte_g_dot(_p(a), int(l[6]), 90, 255, 30)
+        elif 0 <= a[0] < W and 0 <= a[1] < H:
+            orc.g_pixel(a, int(l[6]))
+            eng.lte_g_pixel(_p(a), int(l[6]))
     eng.lte_flush()
     c = np.ctypeslib.as_array(eng.lte_cbuf(), shape=(H, W)).copy()
     z = np.ctypeslib.as_array(eng.lte_zbuf(), shape=(H, W)).copy()
