@@ -377,7 +377,7 @@ def main():
                        if sc.render_type == 4 else
                        f"{args.workload}: {sc.n_polys} textured triangles per frame at {sc.width}x{sc.height}",
                        "parallelism": (f"sort-first row bands x{world}, bands gathered to rank 0" if bands
-                                       else f"frame-parallel x{world}"), "tile": f"{64}x{32}"},
+                                       else f"frame-parallel x{world}"), "tile": "64x32 or 128x32, chosen by the library"},
             "mfragments_per_s": round(frags / dt_max / 1e6, 3),
             "fragments_per_frame": frags // max(args.steps, 1) // (1 if bands else world),
             "stage_ms_per_frame": {k: round(v / max(warm_submits, 1), 4) for k, v in warm_stages.items()},

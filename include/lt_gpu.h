@@ -91,6 +91,11 @@ int lt_set_pipelining(lt_ctx *ctx, int on);
 /* Capacity, in (polygon, tile) references, of the per-submit tile lists.  0 = default
  * (64 per polygon, at least 1M). */
 int lt_set_list_capacity(lt_ctx *ctx, uint64_t refs);
+/* Width of the screen tiles of the fill for the batches submitted next: 64 or 128 pixels (tiles
+ * are 32 rows high), or 0 (default) to let the library choose -- wide tiles once the polygons
+ * drawn between two lt_flush calls averaged 256 depth tests or more.  The frame does not
+ * depend on it.  No counterpart in the reference. */
+int lt_set_tile_width(lt_ctx *ctx, int width);
 
 /* The reference's textured fills advance the light accumulators only where the depth
  * test passes (GraphicsPoly.cpp:485-493, 666-674), so with a light gradient along a span

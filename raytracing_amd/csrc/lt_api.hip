@@ -27,7 +27,10 @@ struct DevBuf {
 
 struct lt_ctx {
     int device = 0;
-    int W = 0, H = 0, tiles_x = 0, tiles_y = 0, ntiles = 0;
+    int W = 0, H = 0, tiles_x = 0, tiles_y = 0, ntiles = 0;     // tile counts for the narrow tile (the larger number)
+    int tile_mode = 0;                             // 0: chosen from what the last batches drew; else TW_NARROW / TW_WIDE
+    bool auto_wide = false;                        // the choice when tile_mode == 0
+    unsigned long long seen_fragments = 0, seen_drawn = 0;
     hipStream_t stream = nullptr;
     int *cbuf = nullptr, *zbuf = nullptr;          // the frame being drawn (own or bound)
     int *own_cbuf = nullptr, *own_zbuf = nullptr;  // allocated by lt_ctx_create
@@ -263,7 +266,12 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.np = np; sa.nv = nv; sa.npv = npv;
     sa.render_type = render_type; sa.log_focus = log_focus; sa.force_linear = force_linear;
     sa.max_edges = max_edges;
-    sa.W = c->W; sa.H = c->H; sa.tiles_x = c->tiles_x; sa.tiles_y = c->tiles_y;
+    // tile width of this batch
+    const int tile_w = c->tile_mode ? c->tile_mode : (c->auto_wide ? TW_WIDE : TW_NARROW);
+    const int twl = tile_w == TW_WIDE ? 7 : 6;
+    const int tiles_x = (c->W + tile_w - 1) / tile_w, ntiles = tiles_x * c->tiles_y;
+    sa.W = c->W; sa.H = c->H; sa.tiles_x = tiles_x; sa.tiles_y = c->tiles_y;
+    sa.tile_w_log = twl;
     sa.emax = emax;
     sa.hdr = (PrimHdr *)w.hdr.p; sa.edges = (int *)w.edges.p;
     sa.prp = want_prp ? (int *)w.prp.p : nullptr;
@@ -280,7 +288,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     sa.cx0 = c->clip.x0; sa.cy0 = c->clip.y0; sa.cx1 = c->clip.x1; sa.cy1 = c->clip.y1;
     // Screens with more tiles than the LDS histogram of the count kernel holds: set-up adds the
     // references itself (with few tiles the adds pile up on the same words and stall set-up).
-    const bool fused = c->ntiles > BIN_MAX_TILES;
+    const bool fused = ntiles > BIN_MAX_TILES;
     sa.tile_count = fused ? (unsigned *)w.tcount.p : nullptr;
     sa.status = c->status;
     launch_setup(gs, dim, screen, sa);
@@ -295,7 +303,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         if ((rc = new_event(c, (hipStream_t)-1, &scan_idx))) return rc;
         scan_ev = c->ev_pool[scan_idx];
     }
-    launch_binning(gs, (const PrimHdr *)w.hdr.p, np, c->tiles_x, c->ntiles, (unsigned *)w.tcount.p,
+    launch_binning(gs, (const PrimHdr *)w.hdr.p, np, twl, tiles_x, ntiles, (unsigned *)w.tcount.p,
                    (unsigned *)w.toffset.p, (unsigned *)w.tcursor.p, (unsigned *)w.list.p, capacity,
                    screen ? nullptr : sa.queue_count, c->status, scan_ev, fused, c->pipelined ? w.geom_done : nullptr);
     if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
@@ -311,7 +319,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     ra.tile_offset = (const unsigned *)w.toffset.p; ra.tile_fill = (const unsigned *)w.tcursor.p;
     ra.tile_list = (const unsigned *)w.list.p; ra.list_capacity = capacity;
     ra.np = np; ra.emax = emax;
-    ra.W = c->W; ra.H = c->H; ra.tiles_x = c->tiles_x; ra.tiles_y = c->tiles_y;
+    ra.W = c->W; ra.H = c->H; ra.tiles_x = tiles_x; ra.tiles_y = c->tiles_y;
     ra.cbuf = c->cbuf; ra.zbuf = c->zbuf;
     ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
     ra.prp = want_prp ? (const int *)w.prp.p : nullptr; ra.log_focus = log_focus;
@@ -325,7 +333,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     const bool ordered_follows = dim == 8 && c->order_mode != LT_ORDER_NEVER;
     if (ordered_follows) {
         if ((rc = stage_begin(c, 4, rs))) return rc;
-        launch_raster(rs, na, ra, nullptr, nullptr);
+        launch_raster(rs, na, tile_w, ra, nullptr, nullptr);
         HIPCHK(c, launch_ordered(rs, ra));
         if ((rc = stage_end(c, 4, rs))) return rc;
         if (c->pipelined) HIPCHK(c, hipEventRecord(w.raster_done, rs));
@@ -334,10 +342,10 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         if ((rc = new_event(c, (hipStream_t)-1, &sp.begin))) return rc;
         if ((rc = new_event(c, (hipStream_t)-1, &sp.end))) return rc;
         c->spans.push_back(sp);
-        launch_raster(rs, na, ra, c->ev_pool[sp.begin], c->ev_pool[sp.end]);
+        launch_raster(rs, na, tile_w, ra, c->ev_pool[sp.begin], c->ev_pool[sp.end]);
         if (c->pipelined) HIPCHK(c, hipEventRecord(w.raster_done, rs));
     } else {
-        launch_raster(rs, na, ra, nullptr, c->pipelined ? w.raster_done : nullptr);
+        launch_raster(rs, na, tile_w, ra, nullptr, c->pipelined ? w.raster_done : nullptr);
     }
     HIPCHK(c, hipGetLastError());
     if (c->pipelined) w.in_use = true;
@@ -434,7 +442,7 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     c->W = width; c->H = height;
     c->band_y0 = 0; c->band_y1 = height;
     c->clip = ClipWindow{0, 0, width - 1, height - 1};     // C_init_clipping defaults, Clipper.h:19-23
-    c->tiles_x = (width + TW - 1) / TW; c->tiles_y = (height + TH - 1) / TH;
+    c->tiles_x = (width + TW_NARROW - 1) / TW_NARROW; c->tiles_y = (height + TH - 1) / TH;
     c->ntiles = c->tiles_x * c->tiles_y;
     size_t n = (size_t)width * height;
 #define CREATECHK(call)                                                                                   \
@@ -532,6 +540,13 @@ int lt_set_pipelining(lt_ctx *c, int on)
     return LT_OK;
 }
 
+int lt_set_tile_width(lt_ctx *c, int width)
+{
+    if (!c || (width != 0 && width != TW_NARROW && width != TW_WIDE)) return fail(c, LT_ERR_ARG, "lt_set_tile_width: 0, %d or %d", TW_NARROW, TW_WIDE);
+    c->tile_mode = width;
+    return LT_OK;
+}
+
 int lt_set_textured_order(lt_ctx *c, int mode)
 {
     if (!c || mode < LT_ORDER_AUTO || mode > LT_ORDER_NEVER) return fail(c, LT_ERR_ARG, "lt_set_textured_order: mode %d", mode);
@@ -603,6 +618,12 @@ int lt_flush(lt_ctx *c)
     if ((rc = collect(c))) return rc;
     Status s;
     if ((rc = read_status(c, &s))) return rc;
+    // Tile width of the batches to come: wide once the polygons drawn since the last look
+    // averaged 256 depth tests or more (a span is walked once per tile it crosses).
+    if (s.polys_drawn >= c->seen_drawn + 256) {
+        c->auto_wide = (s.fragments - c->seen_fragments) / (s.polys_drawn - c->seen_drawn) >= 256;
+        c->seen_fragments = s.fragments; c->seen_drawn = s.polys_drawn;
+    }
     if (s.list_overflow > c->base.list_overflow) {
         c->base.list_overflow = s.list_overflow;
         return fail(c, LT_ERR_CAPACITY,
@@ -691,6 +712,7 @@ int lt_reset_counters(lt_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->base = Status{};
     c->polys_in = 0;
+    c->seen_fragments = 0; c->seen_drawn = 0;
     return LT_OK;
 }
 

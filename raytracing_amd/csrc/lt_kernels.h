@@ -9,9 +9,11 @@ namespace lt {
 
 // Screen tile owned by one workgroup of the fill kernel.  Its depth keys and colours
 // live in LDS for the whole kernel.
-constexpr int TW = 64;            // tile width  (pixels)
 constexpr int TH = 32;            // tile height (rows)
-constexpr int RASTER_THREADS = 256;
+// Tile width: 64 pixels (256 threads a workgroup) or 128 (512 threads).  A span is walked once
+// per tile it crosses, so wide tiles pay off when polygons are wide; narrow tiles leave the
+// set-up kernels of the next batch more room beside the fill.  Chosen per batch.
+constexpr int TW_NARROW = 64, TW_WIDE = 128;
 constexpr int SETUP_THREADS = 128;
 
 // Per-polygon header written by the setup kernel (16 bytes).
@@ -89,6 +91,7 @@ struct SetupArgs {
     int detect_order;
     int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
     int band_y0, band_y1;    // rows [band_y0, band_y1) are drawn by this context (whole screen: 0, H)
+    int tile_w_log;          // log2 of the tile width of this batch (6 or 7)
     int cx0, cy0, cx1, cy1;  // 2-D clip window C_x_clipping_min .. C_y_clipping_max (whole screen: 0, 0, W-1, H-1)
     unsigned *tile_count;    // non-null: set-up counts the tile references itself (no count kernel)
     Status *status;
@@ -143,10 +146,10 @@ void launch_shade_points(hipStream_t s, const ShadeArgs &a, const int *points, c
 void launch_transform(hipStream_t s, const int *m12_dev, const int *from, int *to, int n);
 void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
 // tile lists: count -> exclusive scan -> scatter (count must be zero before the call)
-void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
+void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
                     unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done);
-void launch_raster(hipStream_t s, int na, const RasterArgs &a, hipEvent_t start, hipEvent_t stop);
+void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop);
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a);   // textured batches only
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 

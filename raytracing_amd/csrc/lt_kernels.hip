@@ -502,7 +502,7 @@ constexpr int KIND_FLAT = 2, KIND_SHADED = 4, KIND_TEX_LIN = 8, KIND_TEX_PRP = 9
 // add per touched tile.
 __device__ __forceinline__ void count_tiles(const SetupArgs &a, int by0, int by1, int minx, int maxx)
 {
-    const int tx0 = minx / TW, tx1 = maxx / TW, ty0 = by0 / TH, ty1 = (by1 - 1) / TH;
+    const int tx0 = minx >> a.tile_w_log, tx1 = maxx >> a.tile_w_log, ty0 = by0 / TH, ty1 = (by1 - 1) / TH;
     for (int ty = ty0; ty <= ty1; ty++)
         for (int tx = tx0; tx <= tx1; tx++) atomicAdd(a.tile_count + ty * a.tiles_x + tx, 1u);
 }
@@ -1255,15 +1255,15 @@ constexpr int BIN_THREADS = 512;
 constexpr int BIN_PER_THREAD = 8;
 constexpr int BIN_CHUNK = BIN_THREADS * BIN_PER_THREAD;
 
-__device__ __forceinline__ bool prim_tiles(const int4 h, int &tx0, int &tx1, int &ty0, int &ty1)
+__device__ __forceinline__ bool prim_tiles(const int4 h, int twl, int &tx0, int &tx1, int &ty0, int &ty1)
 {
     if ((h.w & 0xff) == 0) return false;
     int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff, minx = h.y & 0xffff, maxx = (h.y >> 16) & 0xffff;
-    tx0 = minx / TW; tx1 = maxx / TW; ty0 = miny / TH; ty1 = (maxy - 1) / TH;
+    tx0 = minx >> twl; tx1 = maxx >> twl; ty0 = miny / TH; ty1 = (maxy - 1) / TH;
     return true;
 }
 
-__global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+__global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
                                                             int ntiles, unsigned *__restrict__ count)
 {
     __shared__ unsigned hist[BIN_MAX_TILES];
@@ -1275,7 +1275,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
         int poly = base + k * BIN_THREADS + threadIdx.x;
         if (poly < np) {
             int tx0, tx1, ty0, ty1;
-            if (prim_tiles(((const int4 *)hdr)[poly], tx0, tx1, ty0, ty1))
+            if (prim_tiles(((const int4 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
                 for (int ty = ty0; ty <= ty1; ty++)
                     for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * tiles_x + tx], 1u);
         }
@@ -1285,7 +1285,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
         if (hist[i]) atomicAdd(&count[i], hist[i]);
 }
 
-__global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+__global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
                                                               int ntiles, const unsigned *__restrict__ offset,
                                                               unsigned *__restrict__ cursor, unsigned *__restrict__ list,
                                                               unsigned long long capacity)
@@ -1300,7 +1300,7 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__r
         int poly = base + k * BIN_THREADS + threadIdx.x;
         hs[k] = poly < np ? ((const int4 *)hdr)[poly] : make_int4(0, 0, 0, 0);
         int tx0, tx1, ty0, ty1;
-        if (prim_tiles(hs[k], tx0, tx1, ty0, ty1))
+        if (prim_tiles(hs[k], twl, tx0, tx1, ty0, ty1))
             for (int ty = ty0; ty <= ty1; ty++)
                 for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * tiles_x + tx], 1u);
     }
@@ -1314,7 +1314,7 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__r
     for (int k = 0; k < BIN_PER_THREAD; k++) {
         int poly = base + k * BIN_THREADS + threadIdx.x;
         int tx0, tx1, ty0, ty1;
-        if (prim_tiles(hs[k], tx0, tx1, ty0, ty1))
+        if (prim_tiles(hs[k], twl, tx0, tx1, ty0, ty1))
             for (int ty = ty0; ty <= ty1; ty++)
                 for (int tx = tx0; tx <= tx1; tx++) {
                     unsigned slot = atomicAdd(&hist[ty * tiles_x + tx], 1u);
@@ -1324,18 +1324,18 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__r
 }
 
 // direct versions for screens with more tiles than the LDS histogram holds
-__global__ void __launch_bounds__(256) count_direct_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+__global__ void __launch_bounds__(256) count_direct_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
                                                            unsigned *__restrict__ count)
 {
     int poly = blockIdx.x * blockDim.x + threadIdx.x;
     if (poly >= np) return;
     int tx0, tx1, ty0, ty1;
-    if (prim_tiles(((const int4 *)hdr)[poly], tx0, tx1, ty0, ty1))
+    if (prim_tiles(((const int4 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&count[ty * tiles_x + tx], 1u);
 }
 
-__global__ void __launch_bounds__(256) scatter_direct_kernel(const PrimHdr *__restrict__ hdr, int np, int tiles_x,
+__global__ void __launch_bounds__(256) scatter_direct_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
                                                              const unsigned *__restrict__ offset,
                                                              unsigned *__restrict__ cursor, unsigned *__restrict__ list,
                                                              unsigned long long capacity)
@@ -1343,7 +1343,7 @@ __global__ void __launch_bounds__(256) scatter_direct_kernel(const PrimHdr *__re
     int poly = blockIdx.x * blockDim.x + threadIdx.x;
     if (poly >= np) return;
     int tx0, tx1, ty0, ty1;
-    if (prim_tiles(((const int4 *)hdr)[poly], tx0, tx1, ty0, ty1))
+    if (prim_tiles(((const int4 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 int tile = ty * tiles_x + tx;
@@ -1735,11 +1735,12 @@ __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
 // Pixels that no polygon of this batch won keep what the frame held (or the clear
 // colour).  The frame is read (depth only) at most once per tile and written once.
 
-constexpr unsigned HIZ_MIN_REFS = 4 * RASTER_THREADS;      // tile list length from which the coarse depth test is used
+constexpr unsigned HIZ_MIN_REFS = 1024;                   // tile list length from which the coarse depth test is used
 
-template <int NA>
-__global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
+template <int NA, int TW>
+__global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
 {
+    constexpr int RASTER_THREADS = TH * (TW / 8);      // one thread refreshes one 8-pixel run of the coarse table
     constexpr int ESZ = edge_ints(NA);
     // rows are KW keys apart: with a stride of exactly TW every row would start in the same
     // LDS bank, and the lanes of the depth pass walk different rows at similar columns
@@ -1750,7 +1751,6 @@ __global__ void __launch_bounds__(RASTER_THREADS) raster_kernel(RasterArgs a)
     // Keys only ever decrease, so a stale entry is merely conservative: a piece of a span
     // whose smallest depth is greater than the entry cannot lower any key there and is
     // skipped without touching the keys.  Its fragments are counted all the same.
-    static_assert(RASTER_THREADS == TH * (TW / 8), "one thread refreshes one 8-pixel run");
     __shared__ int zmax[TH * (TW / 8)];
     __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 lanes x {edge0, edge1, edge2, {poly, ne, r0, offset}}
 
@@ -2075,33 +2075,39 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
     else hipLaunchKernelGGL((setup_queues_kernel<8>), g, b, 0, s, a);
 }
 
-void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int tiles_x, int ntiles, unsigned *count,
+void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
                     unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done)
 {
     const bool lds = ntiles <= BIN_MAX_TILES;
     if (np > 0 && !counted) {
-        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, tiles_x, ntiles, count);
-        else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, tiles_x, count);
+        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, twl, tiles_x, ntiles, count);
+        else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, twl, tiles_x, count);
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, cursor, ntiles, capacity, queue_count, status);
     if (after_scan) (void)hipEventRecord(after_scan, s);
     if (np > 0) {
         // `done` (may be null) is the scatter's own completion (see launch_raster)
-        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, nullptr, done, 0, hdr, np, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity);
-        else hipExtLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nullptr, done, 0, hdr, np, tiles_x, (const unsigned *)offset, cursor, list, capacity);
+        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity);
+        else hipExtLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, (const unsigned *)offset, cursor, list, capacity);
     }
 }
 
 // `start` / `stop` (either may be null) ride on the kernel's own dispatch: they take its
 // start and completion without a marker of their own in the stream, which would hold the
 // stream for a few microseconds each.
-void launch_raster(hipStream_t s, int na, const RasterArgs &a, hipEvent_t start, hipEvent_t stop)
+void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop)
 {
-    dim3 g(a.tiles_x * a.tiles_y), b(RASTER_THREADS);
-    if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1>), g, b, 0, s, start, stop, 0, a);
-    else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4>), g, b, 0, s, start, stop, 0, a);
-    else hipExtLaunchKernelGGL((raster_kernel<6>), g, b, 0, s, start, stop, 0, a);
+    dim3 g(a.tiles_x * a.tiles_y), b(TH * (tile_w / 8));
+    if (tile_w == 128) {
+        if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1, 128>), g, b, 0, s, start, stop, 0, a);
+        else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 128>), g, b, 0, s, start, stop, 0, a);
+        else hipExtLaunchKernelGGL((raster_kernel<6, 128>), g, b, 0, s, start, stop, 0, a);
+    } else {
+        if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1, 64>), g, b, 0, s, start, stop, 0, a);
+        else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 64>), g, b, 0, s, start, stop, 0, a);
+        else hipExtLaunchKernelGGL((raster_kernel<6, 64>), g, b, 0, s, start, stop, 0, a);
+    }
 }
 
 int ordered_band_rows(int W, int H)

@@ -171,6 +171,10 @@ class Context:
         self._chk(self.L.lt_shade_points(self.h_ctx, _p(s), _p(p), _p(n), p.shape[0], _p(li), li.shape[0], _p(out)))
         return out[:, :3].copy()
 
+    def set_tile_width(self, width):
+        """64, 128, or 0 = chosen by the library"""
+        self._chk(self.L.lt_set_tile_width(self.h_ctx, int(width)))
+
     def set_clip_window(self, minx, miny, maxx, maxy):
         """C_init_clipping for the batches submitted next"""
         self._chk(self.L.lt_set_clip_window(self.h_ctx, int(minx), int(miny), int(maxx), int(maxy)))

@@ -1,0 +1,67 @@
+"""The fill's tile width (lt_set_tile_width: 64, 128 or chosen by the library) does not change the
+frame or the counters: every kind of batch at both widths against the CPU restatement."""
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import oracle.port as P
+    from raytracing_amd import gpu as G
+    return P, G
+
+
+def oracle_frame(P, sc):
+    o = P.Oracle(sc.width, sc.height)
+    for h, (tex, lg) in enumerate(sc.textures):
+        o.set_texture(h, tex, lg)
+    o.clear(0x102030, 255, 255, 255)
+    o.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type, sc.log_focus, sc.force_linear)
+    return o.cbuf().copy(), o.zbuf().copy(), o.counters()
+
+
+SCENES = {
+    "small": lambda: S.gen_c2(60000, 640, 480, 9, radius=8, seed=3),
+    "large": lambda: S.gen_c2(4000, 640, 480, 9, radius=128, seed=4),
+    "odd_screen": lambda: S.gen_c2(20000, 333, 217, 8, radius=40, seed=5),
+    "flat_fuzz": lambda: S.gen_fuzz_polys(1500, 400, 300, 8, 71, render_type=S.M_FLAT),
+    "textured_fuzz": lambda: S.gen_fuzz_polys(1500, 400, 300, 8, 75, render_type=S.M_TEXTURED, textured=True, equal_lights=True),
+    "textured_ordered": lambda: S.gen_fuzz_polys(600, 400, 300, 8, 73, render_type=S.M_TEXTURED, textured=True, equal_lights=False),
+}
+
+
+@pytest.mark.parametrize("width", [64, 128])
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_frame_is_independent_of_tile_width(env, name, width):
+    P, G = env
+    sc = SCENES[name]()
+    oc, oz, ok = oracle_frame(P, sc)
+    ctx = G.Context(sc.width, sc.height)
+    ctx.set_tile_width(width)
+    ctx.clear(P.cl_light(0x102030, 255, 255, 255))
+    ctx.submit_scene(sc)
+    c, z = ctx.readback()
+    assert np.array_equal(c, oc) and np.array_equal(z, oz)
+    k = ctx.counters()
+    assert k["fragments"] == ok["fragments"] and k["polys_drawn"] == ok["polys_drawn"]
+
+
+def test_library_switches_and_frames_stay_equal(env):
+    """large polygons make the library go to wide tiles at the next flush, small ones back; wide
+    screens (more than 8192 narrow tiles: counting inside set-up) included"""
+    P, G = env
+    big = S.gen_c2(3000, 2048, 1100, 10, radius=128, seed=6)
+    small = S.gen_c2(40000, 2048, 1100, 10, radius=6, seed=7)
+    ctx = G.Context(2048, 1100)
+    with pytest.raises(G.LtError):
+        ctx.set_tile_width(96)
+    for sc in (big, big, small, small, big):
+        oc, oz, _ = oracle_frame(P, sc)
+        ctx.clear(P.cl_light(0x102030, 255, 255, 255))
+        ctx.submit_scene(sc)
+        c, z = ctx.readback()                                    # flushes: the next batch may use the other width
+        assert np.array_equal(c, oc) and np.array_equal(z, oz)
