@@ -242,6 +242,7 @@ def main():
                     help="processes of the all-cores CPU baseline (0 = skip it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--tile-width", type=int, default=0, choices=[0, 64, 128], help="fill tile width (0: chosen by the library)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
     args = ap.parse_args()
 
@@ -285,6 +286,8 @@ def main():
         ctx.texture_upload(h, tex, lg)
     if args.no_pipelining:
         ctx.set_pipelining(False)
+    if args.tile_width:
+        ctx.set_tile_width(args.tile_width)
 
     bands = args.split == "bands"
     if bands:
