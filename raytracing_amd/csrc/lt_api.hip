@@ -418,7 +418,7 @@ int check_type(lt_ctx *c, int render_type, int *dim)
     if (render_type == LT_FLAT) *dim = 3;
     else if (render_type == LT_SHADED) *dim = 6;
     else if (render_type == LT_TEXTURED) *dim = 8;
-    else return fail(c, LT_ERR_ARG, "render type %d: only LT_FLAT, LT_SHADED and LT_TEXTURED are drawn by this path", render_type);
+    else return fail(c, LT_ERR_ARG, "render type %d: not LT_FLAT, LT_SHADED or LT_TEXTURED (LT_WIRE is for lt_submit_object only)", render_type);
     return LT_OK;
 }
 

@@ -109,3 +109,41 @@ def test_first_batches_of_fresh_contexts(env):
             c, z = ctx.readback()
             assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
         ctx.close()
+
+
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_stage_timing_and_its_sampling_period(env, pipelined):
+    """lt_set_profiling: all stages, one stage, one stage on every n-th submit; the events ride
+    on the fill's own dispatch and must not change the frame"""
+    P, G = env
+    sc = S.gen_c2(20000, 640, 480, 9, radius=10, seed=31)
+    orc = P.Oracle(640, 480)
+    orc.clear(0, 0, 0, 0)
+    orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type, sc.log_focus)
+    ctx = G.Context(640, 480)
+    ctx.set_pipelining(pipelined)
+
+    def frames(n):
+        for _ in range(n):
+            ctx.clear(0)
+            ctx.submit_scene(sc)
+
+    ctx.set_profiling(True)
+    frames(3)
+    ms, submits = ctx.stage_ms()
+    assert submits == 3 and all(ms[k] > 0 for k in ("setup", "scan", "bin", "fill"))
+    ctx.set_profiling("fill")
+    frames(4)
+    ms, submits = ctx.stage_ms()
+    assert submits == 4 and ms["fill"] > 0 and ms["setup"] == 0
+    ctx.set_profiling("fill", every=4)
+    frames(9)
+    ms, submits = ctx.stage_ms()
+    assert submits in (2, 3) and ms["fill"] > 0              # the batch counter decides which submits are sampled
+    per_fill = ms["fill"] / submits
+    assert 0.001 < per_fill < 5.0
+    ctx.set_profiling(False)
+    frames(1)
+    assert ctx.stage_ms()[1] == 0
+    c, z = ctx.readback()
+    assert np.array_equal(c, orc.cbuf()) and np.array_equal(z, orc.zbuf())
