@@ -96,3 +96,30 @@ def test_benchmark_frame_matches_the_reference_digest(env):
     c, z = ctx.readback()
     assert S.frame_digest(c) == gold["colour"] and S.frame_digest(z) == gold["depth"]
     assert int((z != 2**31 - 1).sum()) == gold["drawn_pixels"]
+
+
+def test_wireframe_of_the_benchmark_object(env):
+    """the 1M-triangle object as a wireframe at 1080p against the CPU restatement (lines are
+    cheap for it), drawn whole and in two halves, at both pipelining settings"""
+    import oracle.port as P
+    torch, G = env
+    sc = S.gen_c2(1_000_000, 1920, 1080, 10, radius=8)
+    orc = P.Oracle(sc.width, sc.height)
+    orc.clear(0, 0, 0, 0)
+    orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, S.M_WIRE, sc.log_focus)
+    d = _dev(torch, sc)
+    half = sc.n_polys // 2
+    for pipelined in (True, False):
+        ctx = G.Context(sc.width, sc.height)
+        ctx.set_pipelining(pipelined)
+        ctx.clear(0)
+        ctx.submit_object_dev(d["verts"], d["polys"], d["pv"], S.M_WIRE, sc.log_focus, matrix=sc.matrix, max_edges=3)
+        c, z = ctx.readback()
+        assert np.array_equal(c, orc.cbuf()) and np.array_equal(z, orc.zbuf())
+        k = ctx.counters()
+        assert k["fragments"] == orc.counters()["fragments"] and k["polys_drawn"] == orc.counters()["polys_drawn"]
+        ctx.clear(0)
+        ctx.submit_object_dev(d["verts"], d["polys"][:half], d["pv"], S.M_WIRE, sc.log_focus, matrix=sc.matrix, max_edges=3)
+        ctx.submit_object_dev(d["verts"], d["polys"][half:], d["pv"], S.M_WIRE, sc.log_focus, matrix=sc.matrix, max_edges=3)
+        c2, z2 = ctx.readback()
+        assert np.array_equal(c2, c) and np.array_equal(z2, z)
