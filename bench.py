@@ -18,6 +18,8 @@ algorithmic bytes of one frame (160 B per triangle + 8 B per pixel) over that ke
 mean duration from HIP events recorded on the library's stream.  `cpu_baseline` times
 the checker on this host's cores: the reference's own code when its prebuilt checker
 library for this screen size travelled with the tree, else the C restatement.
+`large_class` (default workload, one GPU) adds the metric's second triangle class, a few
+C2-large frames drawn after the headline measurement.
 """
 import argparse
 import json
@@ -140,6 +142,31 @@ def cpu_touched_rows(sc):
             "sample": f"1 pass over the full {sc.n_polys}-triangle frame, 1 thread, row tables reset over touched rows only"}
 
 
+def large_class(ctx, torch, dev, tris, frames=5):
+    """The metric's second triangle class (C2-large: vertex offsets of +-128 pixels) on the same
+    context, after the headline measurement: a few frames, host-timed between two flushes."""
+    sc = make_scene("c2-large", tris)
+    d_verts, d_polys, d_pv = (torch.from_numpy(a).to(dev) for a in (sc.verts, sc.polys, sc.polyverts))
+
+    def frame():
+        ctx.clear(0)
+        ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, matrix=sc.matrix, max_edges=3)
+
+    for _ in range(2):
+        frame()
+        ctx.flush()                                  # the library picks its tile width from what it drew
+    ctx.reset_counters()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        frame()
+    ctx.flush()
+    dt = time.perf_counter() - t0
+    frags = ctx.counters()["fragments"]
+    return {"workload": f"c2-large: {tris} Gouraud Z-buffered triangles per frame at 1920x1080", "frames": frames,
+            "ms_per_frame": round(dt / frames * 1e3, 4), "mtris_per_s": round(tris * frames / dt / 1e6, 3),
+            "mfragments_per_s": round(frags / dt / 1e6, 3)}
+
+
 def cpu_all_cores(workload, tris, cores, passes=3):
     """The same frame on `cores` host cores at once: independent processes (the reference is
     not re-entrant), started before this process touches the GPU.  Returns the dict or None."""
@@ -243,6 +270,7 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--tile-width", type=int, default=0, choices=[0, 64, 128], help="fill tile width (0: chosen by the library)")
+    ap.add_argument("--no-large-class", action="store_true", help="skip the C2-large frames after the headline measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
     args = ap.parse_args()
 
@@ -404,6 +432,8 @@ def main():
             if all_cores:
                 out["cpu_baseline_all_cores"] = all_cores
             out["frame_matches_cpu"] = bool(np.array_equal(c, oc) and np.array_equal(z, oz))
+        if args.workload == "c2-small" and world == 1 and not args.no_large_class and not args.host_arrays:
+            out["large_class"] = large_class(ctx, torch, dev, args.tris)
         print(json.dumps(out), flush=True)
 
     if world > 1:
