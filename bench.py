@@ -256,8 +256,8 @@ def bench_shade(args, rank, local_rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2-small")
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--split", default="frames", choices=["frames", "bands"])
