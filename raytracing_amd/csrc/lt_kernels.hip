@@ -1752,7 +1752,9 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
     // whose smallest depth is greater than the entry cannot lower any key there and is
     // skipped without touching the keys.  Its fragments are counted all the same.
     __shared__ int zmax[TH * (TW / 8)];
-    __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 lanes x {edge0, edge1, edge2, {poly, ne, r0, offset}}
+    __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 polygons x {edge0, edge1, edge2, {poly, ne, r0, offset}}
+    // per wave: one bit per row of a round (64 polygons x TH rows), set at the last row of every polygon
+    __shared__ unsigned long long marks[(RASTER_THREADS / 64) * (TH * 64 / 64)];
 
     const int t = threadIdx.x, lane = t & 63;
     const int tile = blockIdx.x;
@@ -1772,6 +1774,7 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
         if (!a.clear_pending && gx < a.W && gy < a.H) z = a.zbuf[(size_t)gy * a.W + gx];
         keys[ly * KW + lx] = depth_key(z, 0u);
     }
+    for (int p = t; p < (RASTER_THREADS / 64) * TH; p += RASTER_THREADS) marks[p] = 0ull;
     __syncthreads();
 
     unsigned long long frags = 0;
@@ -1837,9 +1840,12 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
 
         // the rows of this round's polygons inside the tile are numbered through a wave-wide
         // prefix sum and dealt one row per lane, 64 rows per step, so lanes stay busy
-        // whatever the mix of polygon heights.  A lane publishes its polygon's depth-pass
-        // data in the wave's own LDS staging rows; the lane that draws a row reads the
-        // owner's data back (ordering inside one wave: LDS operations complete in issue order).
+        // whatever the mix of polygon heights.  The live polygons publish their depth-pass
+        // data in the wave's own LDS staging rows, in lane order without gaps, and set the
+        // bit of their last row in the wave's row marks; the lane that draws row r finds
+        // its owner by counting the polygons that end before r -- the marks below r -- and
+        // reads the owner's data back (ordering inside one wave: LDS operations complete
+        // in issue order).
         {
             const int cnt = live ? r1 - r0 : 0;
             int incl = cnt;
@@ -1849,22 +1855,27 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
                 if (lane >= d) incl += o;
             }
             const int total = __shfl(incl, 63);
+            const bool owns = cnt > 0;
+            const unsigned long long owners = __ballot(owns);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(owners >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)owners, 0u));
             int4 *st = stage + (size_t)(t & ~63) * 4;       // this wave's 64 x 4 pieces
-            st[lane * 4 + 0] = make_int4(ed[0].xy1, ed[0].xy2, ed[0].z0, ed[0].zi);
-            st[lane * 4 + 1] = make_int4(ed[1].xy1, ed[1].xy2, ed[1].z0, ed[1].zi);
-            st[lane * 4 + 2] = make_int4(ed[2].xy1, ed[2].xy2, ed[2].z0, ed[2].zi);
-            st[lane * 4 + 3] = make_int4(poly, ne, r0, incl - cnt);
+            unsigned long long *mk = marks + (t >> 6) * TH;
+            const int last = incl - 1;
+            if (owns) {
+                st[rank * 4 + 0] = make_int4(ed[0].xy1, ed[0].xy2, ed[0].z0, ed[0].zi);
+                st[rank * 4 + 1] = make_int4(ed[1].xy1, ed[1].xy2, ed[1].z0, ed[1].zi);
+                st[rank * 4 + 2] = make_int4(ed[2].xy1, ed[2].xy2, ed[2].z0, ed[2].zi);
+                st[rank * 4 + 3] = make_int4(poly, ne, r0, incl - cnt);
+                atomicOr(&mk[last >> 6], 1ull << (last & 63));
+            }
             LDS_WAVE_SYNC();
             for (int rb = 0; rb < total; rb += 64) {
                 const int r = rb + lane;
+                // polygons that end before this step's first row, then those that end inside the step before r
+                const int before = __popcll(__ballot(owns && last < rb));
+                const unsigned long long word = mk[rb >> 6];
                 if (r < total) {
-                    // owner: the last lane whose exclusive offset is <= r
-                    int lo = 0, hi = 63;
-#pragma unroll
-                    for (int it = 0; it < 6; it++) {
-                        const int mid = (lo + hi + 1) >> 1;
-                        if (st[mid * 4 + 3].w <= r) lo = mid; else hi = mid - 1;
-                    }
+                    const int lo = before + __builtin_amdgcn_mbcnt_hi((unsigned)(word >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)word, 0u));
                     const int4 ow = st[lo * 4 + 3];
                     const int opoly = ow.x, one = ow.y, y = ow.z + (r - ow.w);
                     const unsigned id = (unsigned)opoly + 1u;
@@ -1917,6 +1928,8 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
                     }
                 }
             }
+            LDS_WAVE_SYNC();
+            if (lane * 64 < total) mk[lane] = 0ull;      // the marks of this round
             __builtin_amdgcn_wave_barrier();
         }
     }
