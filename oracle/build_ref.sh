@@ -28,7 +28,7 @@ for f in "$REF"/*.cpp "$REF"/*.h; do
 done
 cp "$HERE/shadow/LightTrack.h" "$TMP/LightTrack.h"
 SRCS=""
-for s in Clipp2D Clipp3D Colour EngBase EngPoly EngBcub GraphicsBase GraphicsPoly TransLn; do SRCS="$SRCS $TMP/$s.cpp"; done
+for s in Clipp2D Clipp3D Colour EngBase EngPoly EngBcub GraphicsBase GraphicsPoly TransLn data; do SRCS="$SRCS $TMP/$s.cpp"; done
 SRCS="$SRCS $TMP/$TFILE"
 g++ -shared -fPIC -O2 -w -fpermissive -fwrapv \
     -D_RGB_ -D_32BPP_ -D_FIXED_ -D_Z_BUFFER_ -D_MONO_ \

@@ -22,6 +22,7 @@
 #include "Graphics.h"
 #include "Trans.h"
 #include "Engine.h"
+#include "data.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdarg.h>
@@ -64,6 +65,9 @@ static std::vector<int> g_texture_store[LTREF_MAX_TEXTURES];
 static int g_inited=0;
 
 extern "C" {
+
+/* the scene-description loader (data.cpp:676-781): the exported variable's memory */
+void *ltref_d_data(const char *name) { return D_data((char*)name); }
 
 int ltref_width(void)  { return HW_SCREEN_X_SIZE; }
 int ltref_height(void) { return HW_SCREEN_Y_SIZE; }

@@ -2,6 +2,7 @@
 // the reference-named C++ API: it builds the M_polygon / M_polygon_object structures from
 // the flat scene arrays and calls the mirror exactly as a reference-style program would.
 #include "lt_engine.h"
+#include "lt_data.h"
 #include <stddef.h>
 #include <stdlib.h>
 #include <vector>
@@ -17,6 +18,8 @@ void lte_init(int w, int h)
     CL_init_colour();
     G_init_graphics();
 }
+
+void *lte_d_data(const char *name) { return D_data((char *)name); }
 
 int *lte_cbuf(void) { return (int *)G_c_buffer; }
 int *lte_zbuf(void) { return G_z_buffer; }

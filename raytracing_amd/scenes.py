@@ -397,3 +397,68 @@ def gen_bicubic_patch(seed: int, extent: int = 300, bulge: int = 150, centre=(0,
             c[i * 4 + j, 1] = centre[1] + (i - 1.5) * 2 * extent / 3 + int(rng.ints(-bulge // 4, bulge // 4, 1)[0])
             c[i * 4 + j, 2] = centre[2] + int(rng.ints(-bulge, bulge, 1)[0])
     return c
+
+
+def tracer_polygon_objects(lights, spheres, quad, pcol):
+    """The ray tracer's world of tracer.dat as polygon objects (configuration 1): the quad and
+    three lat/long spheres (32 x 16 triangles), vertex light from the point lights (Lambert,
+    ambient 0.1), for M_SHADED at 640x480.  lights: (x, y, z, r, g, b) each; spheres:
+    (r, g, b, cx, cy, cz, radius) each; quad: float[5][3], the closed vertex list of the
+    file; pcol: the polygon's colour.  The harness defines this tessellation (the reference
+    only ray-traces that world); golden frames pin it."""
+    objs = []
+
+    def shade(p, n):
+        tot = 0.1
+        for (lx, ly, lz, ir, ig, ib) in lights:
+            d = np.array([lx, ly, lz]) - p
+            d = d / np.linalg.norm(d)
+            tot += max(0.0, float(np.dot(d, n))) * ir
+        return int(min(255, max(0, round(255 * tot))))
+
+    # quad (closed list of 5 vertices in the file; 4 edges)
+    qn = np.array([0.0, -1.0, 0.0])
+    verts = [(int(x), int(y), int(z), 0) for (x, y, z) in quad[:4]]
+    recs = []
+    for k in [0, 1, 2, 3, 0]:
+        l = shade(quad[k], qn)
+        recs.append((k, l, l, l, 0, 0))
+    colour = (int(pcol[0] * 255) << 16) | (int(pcol[1] * 255) << 8) | int(pcol[2] * 255)
+    # both windings so that one of them faces the camera
+    polys = [(colour, -1, 4, 0), (colour, -1, 4, 5)]
+    recs2 = [recs[0], recs[3], recs[2], recs[1], recs[0]]
+    objs.append(dict(verts=np.array(verts, np.int32), polys=np.array(polys, np.int32),
+                     polyverts=np.array(recs + recs2, np.int32)))
+    # spheres
+    NLON, NLAT = 32, 16
+    for (cr, cg, cb, cx, cy, cz, rad) in spheres:
+        colour = (min(255, int(cr * 255)) << 16) | (min(255, int(cg * 255)) << 8) | min(255, int(cb * 255))
+        vs, light = [], []
+
+        def add(theta, phi):
+            n = np.array([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)])
+            p = np.array([cx, cy, cz]) + rad * n
+            vs.append((int(round(p[0])), int(round(p[1])), int(round(p[2])), 0))
+            light.append(shade(p, n))
+            return len(vs) - 1
+
+        top = add(0.0, 0.0)
+        rings = [[add(np.pi * i / NLAT, 2 * np.pi * j / NLON) for j in range(NLON)] for i in range(1, NLAT)]
+        bot = add(np.pi, 0.0)
+        tris = []
+        for j in range(NLON):
+            j2 = (j + 1) % NLON
+            tris.append((top, rings[0][j2], rings[0][j]))
+            tris.append((bot, rings[-1][j], rings[-1][j2]))
+            for i in range(NLAT - 2):
+                a, b, c, d = rings[i][j], rings[i][j2], rings[i + 1][j], rings[i + 1][j2]
+                tris.append((a, b, d))
+                tris.append((a, d, c))
+        recs, polys = [], []
+        for (a, b, c) in tris:
+            polys.append((colour, -1, 3, len(recs)))
+            for k in (a, b, c, a):
+                recs.append((k, light[k], light[k], light[k], 0, 0))
+        objs.append(dict(verts=np.array(vs, np.int32), polys=np.array(polys, np.int32),
+                         polyverts=np.array(recs, np.int32)))
+    return objs

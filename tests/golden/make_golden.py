@@ -13,6 +13,8 @@ and expected outputs -- stored as .npz (no pickles) and .json next to this scrip
   c1_scene.npz      configuration 1: the tracer.dat world (quad + three spheres, tessellated
                     and lit by this script) as flat scene arrays, with the reference's frame
   crops.npz         a few raw 32x32 crops of reference frames
+  data_kats.json    what the reference's D_data builds from the .dat files of
+                    tests/test_data_loader.py and from tracer.dat
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -224,65 +226,8 @@ def parse_tracer_dat(path):
 
 
 def c1_scene():
-    """tracer.dat as polygon objects: the quad and three lat/long spheres (32 x 16),
-    vertex light from the two point lights (Lambert, ambient 0.1), M_SHADED, 640x480."""
-    lights, spheres, quad, pcol = parse_tracer_dat(os.path.join(REFDIR, "tracer.dat"))
-    objs = []
-
-    def shade(p, n):
-        tot = 0.1
-        for (lx, ly, lz, ir, ig, ib) in lights:
-            d = np.array([lx, ly, lz]) - p
-            d = d / np.linalg.norm(d)
-            tot += max(0.0, float(np.dot(d, n))) * ir
-        return int(min(255, max(0, round(255 * tot))))
-
-    # quad (closed list of 5 vertices in the file; 4 edges)
-    qn = np.array([0.0, -1.0, 0.0])
-    verts = [(int(x), int(y), int(z), 0) for (x, y, z) in quad[:4]]
-    recs = []
-    for k in [0, 1, 2, 3, 0]:
-        l = shade(quad[k], qn)
-        recs.append((k, l, l, l, 0, 0))
-    colour = (int(pcol[0] * 255) << 16) | (int(pcol[1] * 255) << 8) | int(pcol[2] * 255)
-    # both windings so that one of them faces the camera
-    polys = [(colour, -1, 4, 0), (colour, -1, 4, 5)]
-    recs2 = [recs[0], recs[3], recs[2], recs[1], recs[0]]
-    objs.append(dict(verts=np.array(verts, np.int32), polys=np.array(polys, np.int32),
-                     polyverts=np.array(recs + recs2, np.int32)))
-    # spheres
-    NLON, NLAT = 32, 16
-    for (cr, cg, cb, cx, cy, cz, rad) in spheres:
-        colour = (min(255, int(cr * 255)) << 16) | (min(255, int(cg * 255)) << 8) | min(255, int(cb * 255))
-        vs, light = [], []
-
-        def add(theta, phi):
-            n = np.array([np.sin(theta) * np.cos(phi), np.cos(theta), np.sin(theta) * np.sin(phi)])
-            p = np.array([cx, cy, cz]) + rad * n
-            vs.append((int(round(p[0])), int(round(p[1])), int(round(p[2])), 0))
-            light.append(shade(p, n))
-            return len(vs) - 1
-
-        top = add(0.0, 0.0)
-        rings = [[add(np.pi * i / NLAT, 2 * np.pi * j / NLON) for j in range(NLON)] for i in range(1, NLAT)]
-        bot = add(np.pi, 0.0)
-        tris = []
-        for j in range(NLON):
-            j2 = (j + 1) % NLON
-            tris.append((top, rings[0][j2], rings[0][j]))
-            tris.append((bot, rings[-1][j], rings[-1][j2]))
-            for i in range(NLAT - 2):
-                a, b, c, d = rings[i][j], rings[i][j2], rings[i + 1][j], rings[i + 1][j2]
-                tris.append((a, b, d))
-                tris.append((a, d, c))
-        recs, polys = [], []
-        for (a, b, c) in tris:
-            polys.append((colour, -1, 3, len(recs)))
-            for k in (a, b, c, a):
-                recs.append((k, light[k], light[k], light[k], 0, 0))
-        objs.append(dict(verts=np.array(vs, np.int32), polys=np.array(polys, np.int32),
-                         polyverts=np.array(recs, np.int32)))
-    return objs
+    """tracer.dat as polygon objects (raytracing_amd.scenes.tracer_polygon_objects)."""
+    return S.tracer_polygon_objects(*parse_tracer_dat(os.path.join(REFDIR, "tracer.dat")))
 
 
 def c1_golden():
@@ -301,6 +246,25 @@ def c1_golden():
     out["meta"] = np.array([W, H, LF], np.int32)
     out["colour"] = ref.cbuf().copy()
     out["depth"] = ref.zbuf().copy()
+    return out
+
+
+def data_kats():
+    """The reference's D_data (data.cpp:676-781) on the two files of tests/test_data_loader.py and on tracer.dat."""
+    import ctypes as C
+    import tempfile
+    sys.path.insert(0, os.path.dirname(HERE))
+    import test_data_loader as T
+    ref = T.ref_lib()
+    d = tempfile.mkdtemp()
+    T.write_files(d)
+    cwd = os.getcwd()
+    os.chdir(d)
+    try:
+        out = {"main": T.dump_main(ref.ltref_d_data(b"main.dat")),
+               "tracer": T.dump_world(ref.ltref_d_data(os.path.join(REFDIR, "tracer.dat").encode()))}
+    finally:
+        os.chdir(cwd)
     return out
 
 
@@ -555,6 +519,7 @@ def bench_frame():
 
 def main():
     json.dump(bench_frame(), open(os.path.join(HERE, "bench_frame.json"), "w"), indent=1, sort_keys=True)
+    json.dump(data_kats(), open(os.path.join(HERE, "data_kats.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "shade_kats.npz"), **shade_kats())
     np.savez_compressed(os.path.join(HERE, "normals_kats.npz"), **normals_kats())
     json.dump(wire_kats(), open(os.path.join(HERE, "wire_kats.json"), "w"), indent=1, sort_keys=True)
