@@ -121,8 +121,19 @@ int lt_clear(lt_ctx *ctx, int32_t lit_colour);
 int lt_flush(lt_ctx *ctx);
 /* lt_flush, then copy the frame to host memory (either pointer may be NULL). */
 int lt_readback(lt_ctx *ctx, int32_t *colour, int32_t *depth);
-/* Device addresses of the frame, valid until lt_ctx_destroy; contents are current after lt_flush. */
+/* Device addresses of the frame, valid until lt_ctx_destroy; contents are current after lt_flush.
+ * (The frame stays at these addresses from this call on: see lt_set_frame_overlap.) */
 int lt_framebuffer(lt_ctx *ctx, int32_t **d_colour, int32_t **d_depth);
+/* Two frames in flight.  G_clear (GraphicsBase.cpp:99-111) makes a frame independent of
+ * everything drawn before it, so while the context draws into its own arrays each
+ * lt_clear that follows a draw starts the new frame in the other of two array pairs, on a
+ * fill stream of its own: its fills do not wait for the last fills of the frame before.
+ * What lt_readback / lt_flush / counters show is unchanged (they wait for everything and
+ * read the current frame); a frame that is cleared away without having been read is still
+ * drawn in full.  Not used with a bound frame (lt_bind_framebuffer), with a band
+ * (lt_set_band), without pipelining, or after lt_framebuffer has handed out the frame's
+ * addresses.  Default on; 0 keeps every frame in one pair.  No counterpart in the reference. */
+int lt_set_frame_overlap(lt_ctx *ctx, int on);
 /* Draw into caller-owned device arrays int32[height][width] (both, or both NULL to go
  * back to the context's own frame) instead of the arrays lt_ctx_create allocated: the
  * counterpart of handing the reference other G_c_buffer / G_z_buffer pointers

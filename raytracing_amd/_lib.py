@@ -11,7 +11,7 @@ SO_PATH = os.path.join(_HERE, "libltgpu.so")
 
 EXPORTS = [
     "lt_ctx_create", "lt_ctx_destroy", "lt_last_error", "lt_set_stream", "lt_set_list_capacity",
-    "lt_clear", "lt_flush", "lt_readback", "lt_framebuffer", "lt_get_counters", "lt_reset_counters",
+    "lt_clear", "lt_flush", "lt_readback", "lt_framebuffer", "lt_set_frame_overlap", "lt_get_counters", "lt_reset_counters",
     "lt_texture_upload", "lt_transform", "lt_submit_object", "lt_submit_object_dev",
     "lt_submit_screen_polys", "lt_set_profiling", "lt_get_stage_ms", "lt_set_textured_order",
     "lt_bind_framebuffer", "lt_set_band", "lt_set_pipelining", "lt_shade_object_dev", "lt_shade_object",
@@ -67,6 +67,7 @@ def lib():
     L.lt_shade_points_dev.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp]
     L.lt_shade_points.argtypes = L.lt_shade_points_dev.argtypes
     L.lt_set_pipelining.argtypes = [vp, i32]
+    L.lt_set_frame_overlap.argtypes = [vp, i32]
     L.lt_get_counters.argtypes = [vp, C.POINTER(Counters)]
     L.lt_reset_counters.argtypes = [vp]
     L.lt_texture_upload.argtypes = [vp, i32, vp, i32]

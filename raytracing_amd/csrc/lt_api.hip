@@ -35,6 +35,18 @@ struct lt_ctx {
     hipStream_t stream = nullptr;
     int *cbuf = nullptr, *zbuf = nullptr;          // the frame being drawn (own or bound)
     int *own_cbuf = nullptr, *own_zbuf = nullptr;  // allocated by lt_ctx_create
+    // Two frames in flight: a cleared frame depends on nothing drawn before it, so with the
+    // context's own buffers every lt_clear that follows a draw moves to the other of two
+    // buffer pairs and the other of two fill streams, and the new frame's fills need not wait
+    // for the old frame's (whose last workgroups leave part of the chip idle).  Off while a
+    // caller's frame is bound, while a band is set, once lt_framebuffer has handed out the
+    // buffers' addresses, and with lt_set_frame_overlap(ctx, 0).
+    int *alt_cbuf = nullptr, *alt_zbuf = nullptr;  // second pair, allocated at its first use
+    hipStream_t alt_rs = nullptr;                  // the second pair's fill stream
+    hipEvent_t ev_side = nullptr;
+    bool frame_overlap = true, fb_exposed = false;
+    bool on_alt = false;                           // which of the two own pairs holds the current own frame
+    bool drawn_since_clear = false;
     int band_y0 = 0, band_y1 = 0;                  // rows this context draws
     ClipWindow clip{0, 0, 0, 0};                   // C_x_clipping_min .. C_y_clipping_max for the batches submitted next
     bool clear_pending = false;
@@ -45,18 +57,22 @@ struct lt_ctx {
     uint64_t polys_in = 0;
     uint64_t list_capacity_user = 0;
     int order_mode = 0;                // LT_ORDER_AUTO / ALWAYS / NEVER
-    // Per-batch workspace (grown on demand, reused).  There are two sets: the set-up and
-    // binning of a batch (which do not touch the frame) run on `gs` while the fill of the
-    // batch before it runs on `rs`, each batch taking the set the batch two before it used.
+    // Per-batch workspace (grown on demand, reused).  The set-up and binning of a batch (which
+    // do not touch the frame) run on a geometry stream while the fill of the batch before it
+    // runs on `rs`.  Small batches take the sets in turns of four and the two geometry streams
+    // in turns of two, so that the set-up chains of two batches are in flight at once (the
+    // short binning kernels of one leave most of the chip to the other); batches whose work
+    // arrays are large stay with two sets and one geometry stream.
     struct Work {
         DevBuf hdr, edges, prp, list, tcount, toffset, tcursor, queue, scratch;   // scratch: order flag + sub-queue counters
         DevBuf sq_desc, sq_tuples, sq_queue;                                      // screen queue of the fast set-up kernel
         hipEvent_t geom_done = nullptr, raster_done = nullptr;
         bool in_use = false;
-    } work[2];
+    } work[4];
+    int last_set = 0;                  // the set the batch before took
     unsigned batch_no = 0;
     bool pipelined = true;
-    hipStream_t own_gs = nullptr, own_rs = nullptr;    // internal streams (non-blocking)
+    hipStream_t own_gs = nullptr, own_gs2 = nullptr, own_rs = nullptr;    // internal streams (non-blocking)
     hipStream_t gs = nullptr, rs = nullptr;            // streams in use: own_* or `stream`
     hipEvent_t ev_fork = nullptr;
     DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn;      // staging for host-pointer calls
@@ -103,7 +119,10 @@ int ensure(lt_ctx *c, DevBuf &b, size_t bytes)
     if (bytes <= b.cap) return LT_OK;
     if (b.p) {
         HIPCHK(c, hipStreamSynchronize(c->gs));
+        if (c->own_gs2) HIPCHK(c, hipStreamSynchronize(c->own_gs2));
         HIPCHK(c, hipStreamSynchronize(c->rs));
+        if (c->alt_rs) HIPCHK(c, hipStreamSynchronize(c->alt_rs));
+        if (c->own_rs) HIPCHK(c, hipStreamSynchronize(c->own_rs));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr; b.cap = 0;
@@ -172,7 +191,10 @@ int collect(lt_ctx *c)
 int sync_all(lt_ctx *c)
 {
     HIPCHK(c, hipStreamSynchronize(c->gs));
+    if (c->own_gs2) HIPCHK(c, hipStreamSynchronize(c->own_gs2));
     HIPCHK(c, hipStreamSynchronize(c->rs));
+    if (c->alt_rs) HIPCHK(c, hipStreamSynchronize(c->alt_rs));
+    if (c->own_rs) HIPCHK(c, hipStreamSynchronize(c->own_rs));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LT_OK;
 }
@@ -193,14 +215,14 @@ int read_status(lt_ctx *c, Status *out)
 }
 
 // as ensure(), and a newly allocated array starts at zero
-int ensure_zeroed(lt_ctx *c, DevBuf &b, size_t bytes)
+int ensure_zeroed(lt_ctx *c, DevBuf &b, size_t bytes, hipStream_t first_user)
 {
     if (bytes <= b.cap) return LT_OK;
     int rc = ensure(c, b, bytes);
     if (rc) return rc;
     // on the stream whose kernels use the array first: the context's own streams do not
     // wait for the default stream
-    HIPCHK(c, hipMemsetAsync(b.p, 0, b.cap, c->gs));
+    HIPCHK(c, hipMemsetAsync(b.p, 0, b.cap, first_user));
     return LT_OK;
 }
 
@@ -222,8 +244,11 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if (capacity < (1u << 20)) capacity = 1u << 20;
 
     int rc;
-    lt_ctx::Work &w = c->work[c->batch_no & 1u];
-    hipStream_t gs = c->gs, rs = c->rs;
+    // batches whose work arrays stay small take four sets and both geometry streams in turns
+    const bool deep = c->pipelined && np <= (1 << 21) && capacity <= (1ull << 27);
+    const int set = (int)(c->batch_no % (deep ? 4u : 2u));
+    lt_ctx::Work &w = c->work[set];
+    hipStream_t gs = (deep && (c->batch_no & 1u)) ? c->own_gs2 : c->gs, rs = c->rs;
     if (c->pipelined) {
         // the inputs may have been produced on the caller's stream; an idle stream has
         // nothing to wait for, and every wait costs the set-up stream a few microseconds
@@ -237,7 +262,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         // Fragment-heavy batches gain nothing from overlap: set-up is a twentieth of the fill
         // and the two slow each other down (measured: 1.79 ms per frame one after the other,
         // 2.3-2.5 ms overlapped), so there the set-up waits for the fill before it as well.
-        lt_ctx::Work &prev = c->work[(c->batch_no + 1u) & 1u];
+        lt_ctx::Work &prev = c->work[c->last_set];
         if (c->fragment_heavy && prev.in_use) HIPCHK(c, hipStreamWaitEvent(gs, prev.raster_done, 0));
     }
     if ((rc = ensure(c, w.hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
@@ -246,10 +271,10 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if ((rc = ensure(c, w.list, (size_t)capacity * sizeof(unsigned)))) return rc;
     const bool want_prp = !screen && dim == 8;
     if (want_prp && (rc = ensure(c, w.prp, (size_t)np * PRP_INTS * sizeof(int)))) return rc;
-    if ((rc = ensure_zeroed(c, w.tcount, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
+    if ((rc = ensure_zeroed(c, w.tcount, (size_t)c->ntiles * sizeof(unsigned), gs))) return rc;
     if ((rc = ensure(c, w.toffset, (size_t)(c->ntiles + 1) * sizeof(unsigned)))) return rc;
     if ((rc = ensure(c, w.tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
-    if ((rc = ensure_zeroed(c, w.scratch, kScratchBytes))) return rc;
+    if ((rc = ensure_zeroed(c, w.scratch, kScratchBytes, gs))) return rc;
     const unsigned qcap = setup_queue_cap(np);
     if (!screen && (rc = ensure(c, w.queue, (size_t)qcap * QUEUES * sizeof(uint2)))) return rc;
     if (!screen && (rc = ensure(c, w.sq_queue, (size_t)qcap * QUEUES * sizeof(uint2)))) return rc;
@@ -355,11 +380,13 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     }
     HIPCHK(c, hipGetLastError());
     if (c->pipelined) w.in_use = true;
+    c->last_set = set;
     c->batch_no++;
     if (c->profiling && (c->batch_no - 1) % c->profile_every == 0) c->timed_batches++;
 
     c->clear_pending = false;
     c->frame_defined = true;
+    c->drawn_since_clear = true;
     c->polys_in += (uint64_t)np;
     return LT_OK;
 }
@@ -378,6 +405,14 @@ void fill_band(lt_ctx *c)
 int wire_begin(lt_ctx *c, hipStream_t *s)
 {
     *s = c->rs;
+    c->drawn_since_clear = true;
+    if (c->alt_rs && c->pipelined) {
+        // the per-pixel winner words are shared by both frames in flight: lines wait for
+        // whatever the other frame's stream still holds
+        hipStream_t other = c->rs == c->alt_rs ? c->own_rs : c->alt_rs;
+        HIPCHK(c, hipEventRecord(c->ev_side, other));
+        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_side, 0));
+    }
     if (c->pipelined && hipStreamQuery(c->stream) != hipSuccess) {
         (void)hipGetLastError();
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));       // the inputs may come from the caller's stream
@@ -467,9 +502,11 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     CREATECHK(hipMalloc((void **)&c->status, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMemset(c->status, 0, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipStreamCreateWithFlags(&c->own_gs, hipStreamNonBlocking));
+    CREATECHK(hipStreamCreateWithFlags(&c->own_gs2, hipStreamNonBlocking));
     CREATECHK(hipStreamCreateWithFlags(&c->own_rs, hipStreamNonBlocking));
     c->gs = c->own_gs; c->rs = c->own_rs;
     CREATECHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    CREATECHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     for (lt_ctx::Work &w : c->work) {
         CREATECHK(hipEventCreateWithFlags(&w.geom_done, hipEventDisableTiming));
         CREATECHK(hipEventCreateWithFlags(&w.raster_done, hipEventDisableTiming));
@@ -491,7 +528,10 @@ int lt_ctx_destroy(lt_ctx *c)
     if (!c) return LT_OK;
     (void)hipSetDevice(c->device);
     if (c->gs) (void)hipStreamSynchronize(c->gs);
+    if (c->own_gs2) (void)hipStreamSynchronize(c->own_gs2);
     if (c->rs) (void)hipStreamSynchronize(c->rs);
+    if (c->own_rs) (void)hipStreamSynchronize(c->own_rs);
+    if (c->alt_rs) (void)hipStreamSynchronize(c->alt_rs);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn,
                       &c->line_winner, &c->line_colours, &c->s_lines};
@@ -507,7 +547,12 @@ int lt_ctx_destroy(lt_ctx *c)
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->own_gs) (void)hipStreamDestroy(c->own_gs);
+    if (c->own_gs2) (void)hipStreamDestroy(c->own_gs2);
     if (c->own_rs) (void)hipStreamDestroy(c->own_rs);
+    if (c->alt_rs) (void)hipStreamDestroy(c->alt_rs);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->alt_cbuf) (void)hipFree(c->alt_cbuf);
+    if (c->alt_zbuf) (void)hipFree(c->alt_zbuf);
     for (int i = 0; i < LT_MAX_TEXTURES; i++)
         if (c->tex_data[i]) (void)hipFree(c->tex_data[i]);
     if (c->own_cbuf) (void)hipFree(c->own_cbuf);
@@ -541,7 +586,7 @@ int lt_set_pipelining(lt_ctx *c, int on)
     if ((rc = sync_all(c))) return rc;
     c->pipelined = on != 0;
     c->gs = c->pipelined ? c->own_gs : c->stream;
-    c->rs = c->pipelined ? c->own_rs : c->stream;
+    c->rs = !c->pipelined ? c->stream : (c->cbuf == c->alt_cbuf && c->alt_rs ? c->alt_rs : c->own_rs);
     for (lt_ctx::Work &w : c->work) w.in_use = false;
     return LT_OK;
 }
@@ -592,15 +637,49 @@ int lt_bind_framebuffer(lt_ctx *c, int32_t *d_colour, int32_t *d_depth)
     int rc = use_device(c);
     if (rc) return rc;
     if ((rc = lt_flush(c))) return rc;            // queued work and a pending clear go to the frame they were issued for
-    c->cbuf = d_colour ? d_colour : c->own_cbuf;
-    c->zbuf = d_depth ? d_depth : c->own_zbuf;
+    // unbinding returns to the own frame as it was left, in whichever of the two pairs it is
+    c->cbuf = d_colour ? d_colour : (c->on_alt ? c->alt_cbuf : c->own_cbuf);
+    c->zbuf = d_depth ? d_depth : (c->on_alt ? c->alt_zbuf : c->own_zbuf);
+    if (c->pipelined) c->rs = (!d_colour && c->on_alt) ? c->alt_rs : c->own_rs;
     c->frame_defined = true;                      // the memory holds whatever its owner left there
+    return LT_OK;
+}
+
+int lt_set_frame_overlap(lt_ctx *c, int on)
+{
+    if (!c) return LT_ERR_ARG;
+    c->frame_overlap = on != 0;
+    return LT_OK;
+}
+
+// the frame that starts with this clear goes to the other buffer pair and fill stream
+static int next_frame_side(lt_ctx *c)
+{
+    const bool own = c->cbuf == c->own_cbuf || (c->alt_cbuf && c->cbuf == c->alt_cbuf);
+    if (!c->frame_overlap || !c->pipelined || c->fb_exposed || !own || !c->drawn_since_clear || c->band_y0 > 0 || c->band_y1 < c->H)
+        return LT_OK;
+    int rc = use_device(c);
+    if (rc) return rc;
+    if (!c->alt_cbuf) {
+        const size_t n = (size_t)c->W * c->H;
+        HIPCHK(c, hipMalloc((void **)&c->alt_cbuf, n * sizeof(int)));
+        HIPCHK(c, hipMalloc((void **)&c->alt_zbuf, n * sizeof(int)));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->alt_rs, hipStreamNonBlocking));
+    }
+    const bool to_alt = c->cbuf == c->own_cbuf;
+    c->on_alt = to_alt;
+    c->cbuf = to_alt ? c->alt_cbuf : c->own_cbuf;
+    c->zbuf = to_alt ? c->alt_zbuf : c->own_zbuf;
+    c->rs = to_alt ? c->alt_rs : c->own_rs;
     return LT_OK;
 }
 
 int lt_clear(lt_ctx *c, int32_t lit_colour)
 {
     if (!c) return LT_ERR_ARG;
+    int rc = next_frame_side(c);
+    if (rc) return rc;
+    c->drawn_since_clear = false;
     c->clear_pending = true;
     c->clear_colour = lit_colour;
     c->frame_defined = true;
@@ -684,6 +763,7 @@ int lt_readback(lt_ctx *c, int32_t *colour, int32_t *depth)
 int lt_framebuffer(lt_ctx *c, int32_t **d_colour, int32_t **d_depth)
 {
     if (!c) return LT_ERR_ARG;
+    c->fb_exposed = true;             // the caller may keep the addresses: the frame stays where it is from now on
     if (d_colour) *d_colour = c->cbuf;
     if (d_depth) *d_depth = c->zbuf;
     return LT_OK;
@@ -811,6 +891,7 @@ int lt_shade_object(lt_ctx *c, const int32_t s9[9], int32_t x, int32_t y, int32_
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
+    HIPCHK(c, hipStreamSynchronize(c->own_gs2));
     if ((rc = ensure(c, c->s_verts, (size_t)nv * 16))) return rc;
     if ((rc = ensure(c, c->s_normals, (size_t)nn * 16))) return rc;
     if ((rc = ensure(c, c->s_polys, (size_t)np * 16))) return rc;
@@ -942,6 +1023,7 @@ int lt_submit_object(lt_ctx *c, const int32_t m[12], const int32_t *verts, int n
     int rc = use_device(c);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
+    HIPCHK(c, hipStreamSynchronize(c->own_gs2));
     if ((rc = ensure(c, c->s_verts, (size_t)nv * 16))) return rc;
     if ((rc = ensure(c, c->s_polys, (size_t)np * 16))) return rc;
     if ((rc = ensure(c, c->s_pv, (size_t)npv * 24))) return rc;
@@ -971,6 +1053,7 @@ int lt_submit_screen_polys(lt_ctx *c, int kind, const int32_t *tuples, int ntupl
     if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
     if ((rc = use_device(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
+    HIPCHK(c, hipStreamSynchronize(c->own_gs2));
     if ((rc = ensure(c, c->s_polys, (size_t)n * 16))) return rc;
     if ((rc = ensure(c, c->s_pv, (size_t)ntuples * dim * 4))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->s_polys.p, desc, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));

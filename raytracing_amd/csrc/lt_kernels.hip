@@ -1220,7 +1220,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 // and an empty launch still costs its dispatch, several times over when the chip is busy
 // with the fill of the previous batch.
 template <int DIM>
-__global__ void __launch_bounds__(SETUP_THREADS) setup_queues_kernel(SetupArgs a)
+__global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_kernel(SetupArgs a)
 {
     if (blockIdx.y < QUEUES) {
         SetupArgs q = a;

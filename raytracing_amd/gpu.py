@@ -93,6 +93,10 @@ class Context:
         """overlap a batch's set-up with the fill of the batch before it (default on)"""
         self._chk(self.L.lt_set_pipelining(self.h_ctx, int(on)))
 
+    def set_frame_overlap(self, on):
+        """two frames in flight (a cleared frame starts in the other of two buffer pairs); default on"""
+        self._chk(self.L.lt_set_frame_overlap(self.h_ctx, int(on)))
+
     def set_band(self, y0, y1):
         """this context draws only rows [y0, y1) of the screen"""
         self._chk(self.L.lt_set_band(self.h_ctx, y0, y1))

@@ -1,0 +1,111 @@
+"""Two frames in flight (lt_set_frame_overlap): a cleared frame starts in the other of two
+buffer pairs on a fill stream of its own.  What a caller reads back must not depend on it."""
+import numpy as np
+import pytest
+
+from raytracing_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import oracle.port as P
+    from raytracing_amd import gpu as G
+    return P, G
+
+
+def _oracle_frame(P, W, H, clear, scenes):
+    orc = P.Oracle(W, H)
+    orc.clear(clear, 255, 255, 255)
+    for sc in scenes:
+        orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, None, sc.polyverts, sc.render_type, sc.log_focus)
+    return orc
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_frames_without_a_flush_and_drawing_on_after_a_read(env, overlap):
+    """seven cleared frames back to back (odd and even counts of buffer switches on the way),
+    read back; then two more batches drawn over the frame that was read, with no clear"""
+    import torch
+    P, G = env
+    W, H = 640, 480
+    ctx = G.Context(W, H)
+    ctx.set_frame_overlap(overlap)
+    scenes = [S.gen_c2(4000 + 700 * f, W, H, 9, radius=10 + f, seed=3100 + f) for f in range(9)]
+    dev = [[torch.from_numpy(a).cuda() for a in (sc.verts, sc.polys, sc.polyverts)] for sc in scenes]
+
+    def draw(f):
+        sc, d = scenes[f], dev[f]
+        ctx.submit_object_dev(d[0], d[1], d[2], sc.render_type, sc.log_focus, matrix=sc.matrix, max_edges=3)
+
+    frags = 0
+    for f in range(7):
+        ctx.clear(f * 0x010203)
+        draw(f)
+        frags += _oracle_frame(P, W, H, 0, [scenes[f]]).counters()["fragments"]
+        if f == 3:                                   # a read in the middle: the fourth frame, from whichever pair holds it
+            c, z = ctx.readback()
+            orc = _oracle_frame(P, W, H, 3 * 0x010203, [scenes[3]])
+            assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    c, z = ctx.readback()
+    orc = _oracle_frame(P, W, H, 6 * 0x010203, [scenes[6]])
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert ctx.counters()["fragments"] == frags
+    draw(7)
+    draw(8)
+    c, z = ctx.readback()
+    orc = _oracle_frame(P, W, H, 6 * 0x010203, [scenes[6], scenes[7], scenes[8]])
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+
+
+def test_clear_twice_and_empty_frames(env):
+    """clears with nothing drawn between them, a frame that is only cleared, then a drawn one"""
+    import torch
+    P, G = env
+    W, H = 320, 200
+    ctx = G.Context(W, H)
+    sc = S.gen_c2(3000, W, H, 8, radius=9, seed=3200)
+    d = [torch.from_numpy(a).cuda() for a in (sc.verts, sc.polys, sc.polyverts)]
+    ctx.clear(0x111111)
+    ctx.submit_object_dev(d[0], d[1], d[2], sc.render_type, sc.log_focus, matrix=sc.matrix, max_edges=3)
+    ctx.clear(0x222222)
+    ctx.clear(0x333333)
+    c, z = ctx.readback()
+    assert (c == 0x333333).all() and (z == 2 ** 31 - 1).all()
+    ctx.submit_object_dev(d[0], d[1], d[2], sc.render_type, sc.log_focus, matrix=sc.matrix, max_edges=3)
+    c, z = ctx.readback()
+    orc = _oracle_frame(P, W, H, 0x333333, [sc])
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+
+
+def test_bound_frame_and_back(env):
+    """own frame drawn (in the second pair after two clears), a caller's frame bound and drawn,
+    unbound: the own frame is as it was left, and drawing goes on in it"""
+    import torch
+    P, G = env
+    W, H = 320, 200
+    ctx = G.Context(W, H)
+    a, b = S.gen_c2(2500, W, H, 8, radius=9, seed=3300), S.gen_c2(2500, W, H, 8, radius=9, seed=3301)
+    da = [torch.from_numpy(x).cuda() for x in (a.verts, a.polys, a.polyverts)]
+    db = [torch.from_numpy(x).cuda() for x in (b.verts, b.polys, b.polyverts)]
+    ctx.clear(0)
+    ctx.submit_object_dev(db[0], db[1], db[2], b.render_type, b.log_focus, matrix=b.matrix, max_edges=3)
+    ctx.clear(0x0a0a0a)
+    ctx.submit_object_dev(da[0], da[1], da[2], a.render_type, a.log_focus, matrix=a.matrix, max_edges=3)
+    fc = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    fz = torch.zeros((H, W), dtype=torch.int32, device="cuda")
+    ctx.bind_framebuffer(fc, fz)
+    ctx.clear(0x050505)
+    ctx.submit_object_dev(db[0], db[1], db[2], b.render_type, b.log_focus, matrix=b.matrix, max_edges=3)
+    ctx.flush()
+    orc = _oracle_frame(P, W, H, 0x050505, [b])
+    assert (fz.cpu().numpy() == orc.zbuf()).all() and (fc.cpu().numpy() == orc.cbuf()).all()
+    ctx.bind_framebuffer(None, None)
+    c, z = ctx.readback()
+    orc = _oracle_frame(P, W, H, 0x0a0a0a, [a])
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    ctx.submit_object_dev(db[0], db[1], db[2], b.render_type, b.log_focus, matrix=b.matrix, max_edges=3)
+    c, z = ctx.readback()
+    orc = _oracle_frame(P, W, H, 0x0a0a0a, [a, b])
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
