@@ -457,6 +457,8 @@ def main():
             out["roofline"]["alone"] = {"kernel_ms": round(alone_ms, 4), "achieved": round(frame_bytes / (alone_ms * 1e-3) / 1e9, 2),
                                         "frac": round(frame_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                         "measured_on": "10 frames on one stream after the timed region"}
+            out["roofline"]["note"] = ("kernel_ms is one launch in the timed region, where two frames are in flight and two launches "
+                                       "of this kernel share the chip; `alone` is the same kernel with the chip to itself")
         out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
         vr = valu_roofline(args.workload, sc.n_polys, dom, dom_ms)
         if vr:
