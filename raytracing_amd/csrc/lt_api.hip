@@ -114,16 +114,14 @@ int fail(lt_ctx *c, int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(c, LT_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
     } while (0)
 
+int sync_all(lt_ctx *c);
+
 int ensure(lt_ctx *c, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap) return LT_OK;
     if (b.p) {
-        HIPCHK(c, hipStreamSynchronize(c->gs));
-        if (c->own_gs2) HIPCHK(c, hipStreamSynchronize(c->own_gs2));
-        HIPCHK(c, hipStreamSynchronize(c->rs));
-        if (c->alt_rs) HIPCHK(c, hipStreamSynchronize(c->alt_rs));
-        if (c->own_rs) HIPCHK(c, hipStreamSynchronize(c->own_rs));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int rc = sync_all(c);           // nothing queued may still use the old array
+        if (rc) return rc;
         HIPCHK(c, hipFree(b.p));
         b.p = nullptr; b.cap = 0;
     }
