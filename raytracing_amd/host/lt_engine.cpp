@@ -43,8 +43,15 @@ std::vector<int32_t> q_tuples, q_desc;               // Q_SCREEN
 std::vector<int32_t> q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
 std::vector<int32_t> q_lines;                        // Q_LINES: {x1 y1 z1 x2 y2 z2 lit-colour 0}
 int q_max_edges = 0;
-std::map<const void *, int> g_tex_handles;           // texel pointer -> handle
+// Textures are the caller's memory, read by the reference at draw time (GraphicsPoly.cpp:486).
+// Here a texel array is uploaded once and known by its address; the first use of an address
+// after a batch has been submitted checks a digest of the texels, so that an array whose
+// contents changed -- or a new array that the allocator placed at an old address -- is uploaded
+// again under the same handle.
+struct TexEntry { int handle; int log_size; uint64_t digest; unsigned epoch; };
+std::map<const void *, TexEntry> g_tex_handles;      // texel pointer -> handle
 int g_next_tex = 0;
+unsigned g_tex_epoch = 1;                            // advanced whenever a batch has been submitted
 
 inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
 inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
@@ -64,14 +71,36 @@ void need_ctx()
     if (!g_ctx) HW_error((char *)"(Graphics) G_init_graphics has not been called.\n");
 }
 
+uint64_t texel_digest(const HW_pixel *t, int log_size)
+{
+    // four interleaved multiply-xor chains over the words (one chain would wait for its own multiply)
+    const size_t n = (size_t)1 << (2 * log_size);
+    uint64_t h[4] = {0xcbf29ce484222325ull, 0x9e3779b97f4a7c15ull, 0xbf58476d1ce4e5b9ull, 0x94d049bb133111ebull};
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        for (int k = 0; k < 4; k++) h[k] = (h[k] ^ (uint32_t)t[i + k]) * 0x100000001b3ull;
+    for (; i < n; i++) h[0] = (h[0] ^ (uint32_t)t[i]) * 0x100000001b3ull;
+    return h[0] ^ (h[1] << 1) ^ (h[2] << 2) ^ (h[3] << 3) ^ (uint64_t)log_size;
+}
+
 int texture_handle(HW_pixel *texels, int log_size)
 {
     auto it = g_tex_handles.find(texels);
-    if (it != g_tex_handles.end()) return it->second;
+    if (it != g_tex_handles.end() && it->second.epoch == g_tex_epoch && it->second.log_size == log_size) return it->second.handle;
+    const uint64_t d = texel_digest(texels, log_size);
+    if (it != g_tex_handles.end()) {
+        TexEntry &e = it->second;
+        if (e.digest != d || e.log_size != log_size) {
+            chk(lt_texture_upload(g_ctx, e.handle, texels, log_size));     // waits for the batches that read the old texels
+            e.digest = d; e.log_size = log_size;
+        }
+        e.epoch = g_tex_epoch;
+        return e.handle;
+    }
     if (g_next_tex >= LT_MAX_TEXTURES) HW_error((char *)"(GPU) too many textures.\n");
-    int h = g_next_tex++;
+    const int h = g_next_tex++;
     chk(lt_texture_upload(g_ctx, h, texels, log_size));
-    g_tex_handles[texels] = h;
+    g_tex_handles[texels] = TexEntry{h, log_size, d, g_tex_epoch};
     return h;
 }
 
@@ -89,6 +118,7 @@ void run_queue()
         chk(lt_submit_lines(g_ctx, q_lines.data(), (int)(q_lines.size() / 8)));
     }
     q_kind = Q_NONE;
+    g_tex_epoch++;
     q_lines.clear();
     q_tuples.clear(); q_desc.clear(); q_verts.clear(); q_polys.clear(); q_aux.clear(); q_pv.clear();
     q_max_edges = 0;

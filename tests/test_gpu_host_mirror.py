@@ -99,3 +99,28 @@ def test_shade_polygon_object(eng):
     eng.lte_shade_object(_p(v), v.shape[0], _p(n), n.shape[0], _p(po), _p(aux), _p(pv), _p(pn), po.shape[0],
                          *pos, *ang, _p(li), li.shape[0])
     assert np.array_equal(pv, want_pv) and np.array_equal(aux[:, :3], want_pa[:, :3])
+
+
+def test_texels_changed_in_place_are_seen(eng):
+    """The reference reads texel memory at draw time: the same array with new contents in the
+    next frame draws the new texels (the mirror knows an uploaded texture by its address)."""
+    import oracle.port as P
+    sc = S.gen_fuzz_polys(60, W, H, 7, 4321, render_type=S.M_TEXTURED, textured=True, equal_lights=True)
+    tex = np.ascontiguousarray(sc.textures[0][0], dtype=np.int32).copy()
+    lg = sc.textures[0][1]
+    eng.lte_set_texture(1, _p(tex), lg)
+    sc.polys[:, 1] = 1
+    cam, obj = (0, 0, 0, 0, 0, 0), (0, 0, 0, 0, 0, 30)
+    m = P.make_matrix(cam, obj, 0)
+    for rnd in range(2):
+        orc = P.Oracle(W, H)
+        orc.set_texture(1, tex, lg)
+        orc.clear(0, 0, 0, 0)
+        orc.render_polys(P.transform(m, sc.verts), sc.polys, sc.polyaux, sc.polyverts, S.M_TEXTURED, sc.log_focus)
+        eng.lte_clear(0, 0, 0, 0)
+        v, po, pa, pv = sc.verts.copy(), sc.polys.copy(), sc.polyaux.copy(), sc.polyverts.copy()
+        eng.lte_render_object(_p(v), v.shape[0], _p(po), _p(pa), _p(pv), po.shape[0], S.M_TEXTURED, *cam, sc.log_focus,
+                              *obj[3:], *obj[:3])
+        c, z = _frame(eng)
+        assert np.array_equal(z, orc.zbuf()) and np.array_equal(c, orc.cbuf()), rnd
+        tex[:] = S.make_texture(99, lg)             # same address, other texels
