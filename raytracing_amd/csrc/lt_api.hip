@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,39 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
 };
+
+}  // namespace
+
+// Work arrays of lt_submit_object_dev_noalloc: one array per GPU, held from the moment the
+// library's code is loaded on it until the process ends.  In host code the name below is only
+// a handle for hipGetSymbolAddress, never a device address: lt_ctx_create asks once per device
+// for the array's address there and every later use goes through that pointer.
+static __device__ __align__(256) unsigned char scratch[LT_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+
+struct NoAllocDevice {
+    void *ptr = nullptr;               // address of `scratch` on this device
+    hipEvent_t done = nullptr;         // end of the last batch that used it
+    bool pending = false;
+};
+NoAllocDevice g_noalloc[MAX_DEVICES];
+std::mutex g_noalloc_mutex;
+
+// once per device, with that device current
+hipError_t noalloc_init(int device)
+{
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    NoAllocDevice &d = g_noalloc[device];
+    if (d.ptr) return hipSuccess;
+    void *p = nullptr;
+    hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!p) return hipErrorInvalidSymbol;
+    if (!d.done && (e = hipEventCreateWithFlags(&d.done, hipEventDisableTiming)) != hipSuccess) return e;
+    d.ptr = p;
+    return hipSuccess;
+}
 
 }  // namespace
 
@@ -230,20 +264,187 @@ int use_device(lt_ctx *c)
     return LT_OK;
 }
 
-// set-up -> scan -> bin -> fill for one batch whose polygon data is on the device
+// Sizes of one batch's work arrays.
+struct BatchPlan {
+    int emax = 0, max_edges = 0;
+    uint64_t capacity = 0;             // tile list entries
+    unsigned qcap = 0;                 // entries per set-up sub-queue
+    bool want_prp = false;
+    size_t hdr = 0, edges = 0, list = 0, prp = 0, tcount = 0, toffset = 0, tcursor = 0, flags = 0;
+    size_t queue = 0, sq_queue = 0, sq_desc = 0, sq_tuples = 0;      // object batches only
+};
+
+// The work arrays themselves: a context's work set, or pieces of the static scratch array.
+struct WorkArrays {
+    PrimHdr *hdr = nullptr;
+    int *edges = nullptr, *prp = nullptr;
+    unsigned *list = nullptr, *tcount = nullptr, *toffset = nullptr, *tcursor = nullptr;
+    int *flags = nullptr;              // order flag (first 256 bytes), then the set-up sub-queue counters
+    uint2 *queue = nullptr, *sq_queue = nullptr;
+    int *sq_desc = nullptr, *sq_tuples = nullptr;
+};
+
+BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edges, uint64_t min_capacity)
+{
+    BatchPlan p;
+    const int na = dim - 2;
+    if (max_edges <= 0 || max_edges > 15) max_edges = 15;
+    p.max_edges = max_edges;
+    p.emax = (screen ? 2 : 4) * max_edges;
+    if (p.emax > 15) p.emax = 15;
+    p.capacity = c->list_capacity_user ? c->list_capacity_user : (uint64_t)np * 64u;
+    if (p.capacity < min_capacity) p.capacity = min_capacity;
+    p.qcap = setup_queue_cap(np);
+    p.want_prp = !screen && dim == 8;
+    p.hdr = (size_t)np * sizeof(PrimHdr);
+    // one record (header copy + edges 0..2) per slot, then the planes of edges 3 and up
+    p.edges = (size_t)np * (16 + (p.emax < 3 ? 3 : p.emax) * edge_ints(na) * sizeof(int));
+    p.list = (size_t)p.capacity * sizeof(unsigned);
+    p.prp = p.want_prp ? (size_t)np * PRP_INTS * sizeof(int) : 0;
+    p.tcount = (size_t)c->ntiles * sizeof(unsigned);
+    p.toffset = (size_t)(c->ntiles + 1) * sizeof(unsigned);
+    p.tcursor = (size_t)c->ntiles * sizeof(unsigned);
+    p.flags = kScratchBytes;
+    if (!screen) {
+        p.queue = (size_t)p.qcap * QUEUES * sizeof(uint2);
+        p.sq_queue = p.queue;
+        p.sq_desc = (size_t)p.qcap * QUEUES * sizeof(int4);
+        p.sq_tuples = (size_t)p.qcap * QUEUES * 4 * dim * sizeof(int);
+    }
+    return p;
+}
+
+// set-up -> scan -> bin -> fill for one batch whose polygon data and work arrays are on the
+// device.  Set-up and binning are issued on gs, the fill on rs.  geom_done / raster_done (both
+// or neither): the hand-over events between the two streams and the "work arrays free" signal.
+// The tile counts and the sub-queue counters in `wa` must be zero.
+int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_t gs, hipStream_t rs, hipEvent_t geom_done,
+                hipEvent_t raster_done, bool timing, bool screen, int dim, const int32_t *m, const int *d_verts, int nv,
+                const int *d_polys, const int *d_aux, int np, const int *d_pv, int npv, int render_type, int log_focus,
+                int force_linear)
+{
+    const int na = dim - 2;
+    const int emax = pl.emax;
+    const uint64_t capacity = pl.capacity;
+    const bool want_prp = pl.want_prp;
+    const int saved_profiling = c->profiling;
+    if (!timing) c->profiling = 0;
+    struct Restore { lt_ctx *c; int v; ~Restore() { c->profiling = v; } } restore{c, saved_profiling};
+    int rc;
+    int *order_flag = wa.flags;
+
+    // the transform is applied inside the setup kernel: its stage is empty
+    if ((rc = stage_begin(c, 0, gs))) return rc;
+    if ((rc = stage_end(c, 0, gs))) return rc;
+    if ((rc = stage_begin(c, 1, gs))) return rc;
+    const int order_gen = (int)(c->batch_no % 0x7fffffffu) + 1;
+
+    SetupArgs sa{};
+    sa.use_matrix = m ? 1 : 0;
+    if (m) for (int i = 0; i < 12; i++) sa.m[i] = m[i];
+    sa.verts = d_verts; sa.polys = d_polys; sa.polyaux = d_aux; sa.polyverts = d_pv;
+    sa.np = np; sa.nv = nv; sa.npv = npv;
+    sa.render_type = render_type; sa.log_focus = log_focus; sa.force_linear = force_linear;
+    sa.max_edges = pl.max_edges;
+    // tile width of this batch
+    const int tile_w = c->tile_mode ? c->tile_mode : (c->auto_wide ? TW_WIDE : TW_NARROW);
+    const int twl = tile_w == TW_WIDE ? 7 : 6;
+    const int tiles_x = (c->W + tile_w - 1) / tile_w, ntiles = tiles_x * c->tiles_y;
+    sa.W = c->W; sa.H = c->H; sa.tiles_x = tiles_x; sa.tiles_y = c->tiles_y;
+    sa.tile_w_log = twl;
+    sa.emax = emax;
+    sa.hdr = wa.hdr; sa.edges = wa.edges;
+    sa.prp = want_prp ? wa.prp : nullptr;
+    sa.order_flag = order_flag; sa.order_gen = order_gen; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
+    // object batches: unclipped triangles take the fast kernel, the rest go through sub-queues
+    sa.queue = screen ? nullptr : wa.queue;
+    sa.queue_count = (unsigned *)(order_flag + 64);      // behind the order flag
+    sa.queue_cap = pl.qcap;
+    sa.queue_index_limit = (unsigned)np;
+    sa.count_drawn = 1;
+    sa.sq_desc = wa.sq_desc; sa.sq_tuples = wa.sq_tuples; sa.sq_queue = wa.sq_queue;
+    sa.sq_count = sa.queue_count + QUEUES * QUEUE_COUNT_STRIDE;
+    sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
+    sa.cx0 = c->clip.x0; sa.cy0 = c->clip.y0; sa.cx1 = c->clip.x1; sa.cy1 = c->clip.y1;
+    // Screens with more tiles than the LDS histogram of the count kernel holds: set-up adds the
+    // references itself (with few tiles the adds pile up on the same words and stall set-up).
+    const bool fused = ntiles > BIN_MAX_TILES;
+    sa.tile_count = fused ? wa.tcount : nullptr;
+    sa.status = c->status;
+    launch_setup(gs, dim, screen, sa);
+    if ((rc = stage_end(c, 1, gs))) return rc;
+
+    // count + scan are the "scan" stage, the scatter is the "bin" stage; the event between
+    // them is recorded inside launch_binning
+    if ((rc = stage_begin(c, 2, gs))) return rc;
+    hipEvent_t scan_ev = nullptr;
+    size_t scan_idx = 0;
+    if (timed(c, 2) || timed(c, 3)) {
+        if ((rc = new_event(c, (hipStream_t)-1, &scan_idx))) return rc;
+        scan_ev = c->ev_pool[scan_idx];
+    }
+    launch_binning(gs, wa.hdr, np, twl, tiles_x, ntiles, wa.tcount, wa.toffset, wa.tcursor, wa.list, capacity,
+                   screen ? nullptr : sa.queue_count, c->status, scan_ev, fused, geom_done);
+    if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
+    if (timed(c, 3)) {
+        lt_ctx::Span sp{3, scan_idx, 0};
+        c->spans.push_back(sp);
+        if ((rc = stage_end(c, 3, gs))) return rc;
+    }
+    if (geom_done) HIPCHK(c, hipStreamWaitEvent(rs, geom_done, 0));      // the scatter's completion
+
+    RasterArgs ra{};
+    ra.hdr = wa.hdr; ra.edges = wa.edges;
+    ra.tile_offset = wa.toffset; ra.tile_fill = wa.tcursor;
+    ra.tile_list = wa.list; ra.list_capacity = capacity;
+    ra.np = np; ra.emax = emax;
+    ra.W = c->W; ra.H = c->H; ra.tiles_x = tiles_x; ra.tiles_y = c->tiles_y;
+    ra.cbuf = c->cbuf; ra.zbuf = c->zbuf;
+    ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
+    ra.prp = want_prp ? wa.prp : nullptr; ra.log_focus = log_focus;
+    ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
+    ra.order_flag = order_flag; ra.order_gen = order_gen;
+    ra.force_order = (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0;
+    ra.band_y0 = c->band_y0; ra.band_y1 = c->band_y1;
+    ra.status = c->status;
+    // The fill's events are its own dispatch's where no other kernel follows it: its start
+    // and end for the stage timing, else its completion as this work set's "free" signal.
+    const bool ordered_follows = dim == 8 && c->order_mode != LT_ORDER_NEVER;
+    if (ordered_follows) {
+        if ((rc = stage_begin(c, 4, rs))) return rc;
+        launch_raster(rs, na, tile_w, ra, nullptr, nullptr);
+        HIPCHK(c, launch_ordered(rs, ra, c->device));
+        if ((rc = stage_end(c, 4, rs))) return rc;
+        if (raster_done) HIPCHK(c, hipEventRecord(raster_done, rs));
+    } else if (timed(c, 4)) {
+        lt_ctx::Span sp{4, 0, 0};
+        if ((rc = new_event(c, (hipStream_t)-1, &sp.begin))) return rc;
+        if ((rc = new_event(c, (hipStream_t)-1, &sp.end))) return rc;
+        c->spans.push_back(sp);
+        launch_raster(rs, na, tile_w, ra, c->ev_pool[sp.begin], c->ev_pool[sp.end]);
+        if (raster_done) HIPCHK(c, hipEventRecord(raster_done, rs));
+    } else {
+        launch_raster(rs, na, tile_w, ra, nullptr, raster_done);
+    }
+    HIPCHK(c, hipGetLastError());
+    c->batch_no++;
+    if (timing && c->profiling && (c->batch_no - 1) % c->profile_every == 0) c->timed_batches++;
+
+    c->clear_pending = false;
+    c->frame_defined = true;
+    c->drawn_since_clear = true;
+    c->polys_in += (uint64_t)np;
+    return LT_OK;
+}
+
+// One batch through a work set of the context (grown on demand).
 int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_verts, int nv, const int *d_polys, const int *d_aux,
               int np, const int *d_pv, int npv, int render_type, int log_focus, int force_linear, int max_edges)
 {
-    const int na = dim - 2;
-    if (max_edges <= 0 || max_edges > 15) max_edges = 15;
-    int emax = (screen ? 2 : 4) * max_edges;
-    if (emax > 15) emax = 15;
-    uint64_t capacity = c->list_capacity_user ? c->list_capacity_user : (uint64_t)np * 64u;
-    if (capacity < (1u << 20)) capacity = 1u << 20;
-
+    const BatchPlan pl = plan_batch(c, screen, dim, np, max_edges, 1u << 20);
     int rc;
     // batches whose work arrays stay small take four sets and both geometry streams in turns
-    const bool deep = c->pipelined && np <= (1 << 21) && capacity <= (1ull << 27);
+    const bool deep = c->pipelined && np <= (1 << 21) && pl.capacity <= (1ull << 27);
     const int set = (int)(c->batch_no % (deep ? 4u : 2u));
     lt_ctx::Work &w = c->work[set];
     hipStream_t gs = (deep && (c->batch_no & 1u)) ? c->own_gs2 : c->gs, rs = c->rs;
@@ -263,129 +464,31 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         lt_ctx::Work &prev = c->work[c->last_set];
         if (c->fragment_heavy && prev.in_use) HIPCHK(c, hipStreamWaitEvent(gs, prev.raster_done, 0));
     }
-    if ((rc = ensure(c, w.hdr, (size_t)np * sizeof(PrimHdr)))) return rc;
-    // one record (header copy + edges 0..2) per slot, then the planes of edges 3 and up
-    if ((rc = ensure(c, w.edges, (size_t)np * (16 + (emax < 3 ? 3 : emax) * edge_ints(na) * sizeof(int))))) return rc;
-    if ((rc = ensure(c, w.list, (size_t)capacity * sizeof(unsigned)))) return rc;
-    const bool want_prp = !screen && dim == 8;
-    if (want_prp && (rc = ensure(c, w.prp, (size_t)np * PRP_INTS * sizeof(int)))) return rc;
-    if ((rc = ensure_zeroed(c, w.tcount, (size_t)c->ntiles * sizeof(unsigned), gs))) return rc;
-    if ((rc = ensure(c, w.toffset, (size_t)(c->ntiles + 1) * sizeof(unsigned)))) return rc;
-    if ((rc = ensure(c, w.tcursor, (size_t)c->ntiles * sizeof(unsigned)))) return rc;
-    if ((rc = ensure_zeroed(c, w.scratch, kScratchBytes, gs))) return rc;
-    const unsigned qcap = setup_queue_cap(np);
-    if (!screen && (rc = ensure(c, w.queue, (size_t)qcap * QUEUES * sizeof(uint2)))) return rc;
-    if (!screen && (rc = ensure(c, w.sq_queue, (size_t)qcap * QUEUES * sizeof(uint2)))) return rc;
-    if (!screen && (rc = ensure(c, w.sq_desc, (size_t)qcap * QUEUES * sizeof(int4)))) return rc;
-    if (!screen && (rc = ensure(c, w.sq_tuples, (size_t)qcap * QUEUES * 4 * dim * sizeof(int)))) return rc;
-    int *order_flag = (int *)w.scratch.p;
-
-    // the transform is applied inside the setup kernel: its stage is empty
-    if ((rc = stage_begin(c, 0, gs))) return rc;
-    if ((rc = stage_end(c, 0, gs))) return rc;
-    if ((rc = stage_begin(c, 1, gs))) return rc;
-    // the tile counts and the sub-queue counters are zero here: allocated so, and the scan
-    // kernel of the batch that used them last has reset them
-    const int order_gen = (int)(c->batch_no % 0x7fffffffu) + 1;
-
-    SetupArgs sa{};
-    sa.use_matrix = m ? 1 : 0;
-    if (m) for (int i = 0; i < 12; i++) sa.m[i] = m[i];
-    sa.verts = d_verts; sa.polys = d_polys; sa.polyaux = d_aux; sa.polyverts = d_pv;
-    sa.np = np; sa.nv = nv; sa.npv = npv;
-    sa.render_type = render_type; sa.log_focus = log_focus; sa.force_linear = force_linear;
-    sa.max_edges = max_edges;
-    // tile width of this batch
-    const int tile_w = c->tile_mode ? c->tile_mode : (c->auto_wide ? TW_WIDE : TW_NARROW);
-    const int twl = tile_w == TW_WIDE ? 7 : 6;
-    const int tiles_x = (c->W + tile_w - 1) / tile_w, ntiles = tiles_x * c->tiles_y;
-    sa.W = c->W; sa.H = c->H; sa.tiles_x = tiles_x; sa.tiles_y = c->tiles_y;
-    sa.tile_w_log = twl;
-    sa.emax = emax;
-    sa.hdr = (PrimHdr *)w.hdr.p; sa.edges = (int *)w.edges.p;
-    sa.prp = want_prp ? (int *)w.prp.p : nullptr;
-    sa.order_flag = order_flag; sa.order_gen = order_gen; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
-    // object batches: unclipped triangles take the fast kernel, the rest go through sub-queues
-    sa.queue = screen ? nullptr : (uint2 *)w.queue.p;
-    sa.queue_count = (unsigned *)(order_flag + 64);      // behind the order flag in the small device scratch
-    sa.queue_cap = qcap;
-    sa.queue_index_limit = (unsigned)np;
-    sa.count_drawn = 1;
-    sa.sq_desc = (int *)w.sq_desc.p; sa.sq_tuples = (int *)w.sq_tuples.p; sa.sq_queue = (uint2 *)w.sq_queue.p;
-    sa.sq_count = sa.queue_count + QUEUES * QUEUE_COUNT_STRIDE;
-    sa.band_y0 = c->band_y0; sa.band_y1 = c->band_y1;
-    sa.cx0 = c->clip.x0; sa.cy0 = c->clip.y0; sa.cx1 = c->clip.x1; sa.cy1 = c->clip.y1;
-    // Screens with more tiles than the LDS histogram of the count kernel holds: set-up adds the
-    // references itself (with few tiles the adds pile up on the same words and stall set-up).
-    const bool fused = ntiles > BIN_MAX_TILES;
-    sa.tile_count = fused ? (unsigned *)w.tcount.p : nullptr;
-    sa.status = c->status;
-    launch_setup(gs, dim, screen, sa);
-    if ((rc = stage_end(c, 1, gs))) return rc;
-
-    // count + scan are the "scan" stage, the scatter is the "bin" stage; the event between
-    // them is recorded inside launch_binning
-    if ((rc = stage_begin(c, 2, gs))) return rc;
-    hipEvent_t scan_ev = nullptr;
-    size_t scan_idx = 0;
-    if (timed(c, 2) || timed(c, 3)) {
-        if ((rc = new_event(c, (hipStream_t)-1, &scan_idx))) return rc;
-        scan_ev = c->ev_pool[scan_idx];
-    }
-    launch_binning(gs, (const PrimHdr *)w.hdr.p, np, twl, tiles_x, ntiles, (unsigned *)w.tcount.p,
-                   (unsigned *)w.toffset.p, (unsigned *)w.tcursor.p, (unsigned *)w.list.p, capacity,
-                   screen ? nullptr : sa.queue_count, c->status, scan_ev, fused, c->pipelined ? w.geom_done : nullptr);
-    if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
-    if (timed(c, 3)) {
-        lt_ctx::Span sp{3, scan_idx, 0};
-        c->spans.push_back(sp);
-        if ((rc = stage_end(c, 3, gs))) return rc;
-    }
-    if (c->pipelined) HIPCHK(c, hipStreamWaitEvent(rs, w.geom_done, 0));      // the scatter's completion
-
-    RasterArgs ra{};
-    ra.hdr = (const PrimHdr *)w.hdr.p; ra.edges = (const int *)w.edges.p;
-    ra.tile_offset = (const unsigned *)w.toffset.p; ra.tile_fill = (const unsigned *)w.tcursor.p;
-    ra.tile_list = (const unsigned *)w.list.p; ra.list_capacity = capacity;
-    ra.np = np; ra.emax = emax;
-    ra.W = c->W; ra.H = c->H; ra.tiles_x = tiles_x; ra.tiles_y = c->tiles_y;
-    ra.cbuf = c->cbuf; ra.zbuf = c->zbuf;
-    ra.clear_pending = c->clear_pending ? 1 : 0; ra.clear_colour = c->clear_colour;
-    ra.prp = want_prp ? (const int *)w.prp.p : nullptr; ra.log_focus = log_focus;
-    ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
-    ra.order_flag = order_flag; ra.order_gen = order_gen;
-    ra.force_order = (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0;
-    ra.band_y0 = c->band_y0; ra.band_y1 = c->band_y1;
-    ra.status = c->status;
-    // The fill's events are its own dispatch's where no other kernel follows it: its start
-    // and end for the stage timing, else its completion as this work set's "free" signal.
-    const bool ordered_follows = dim == 8 && c->order_mode != LT_ORDER_NEVER;
-    if (ordered_follows) {
-        if ((rc = stage_begin(c, 4, rs))) return rc;
-        launch_raster(rs, na, tile_w, ra, nullptr, nullptr);
-        HIPCHK(c, launch_ordered(rs, ra));
-        if ((rc = stage_end(c, 4, rs))) return rc;
-        if (c->pipelined) HIPCHK(c, hipEventRecord(w.raster_done, rs));
-    } else if (timed(c, 4)) {
-        lt_ctx::Span sp{4, 0, 0};
-        if ((rc = new_event(c, (hipStream_t)-1, &sp.begin))) return rc;
-        if ((rc = new_event(c, (hipStream_t)-1, &sp.end))) return rc;
-        c->spans.push_back(sp);
-        launch_raster(rs, na, tile_w, ra, c->ev_pool[sp.begin], c->ev_pool[sp.end]);
-        if (c->pipelined) HIPCHK(c, hipEventRecord(w.raster_done, rs));
-    } else {
-        launch_raster(rs, na, tile_w, ra, nullptr, c->pipelined ? w.raster_done : nullptr);
-    }
-    HIPCHK(c, hipGetLastError());
+    if ((rc = ensure(c, w.hdr, pl.hdr))) return rc;
+    if ((rc = ensure(c, w.edges, pl.edges))) return rc;
+    if ((rc = ensure(c, w.list, pl.list))) return rc;
+    if (pl.want_prp && (rc = ensure(c, w.prp, pl.prp))) return rc;
+    // the tile counts and the sub-queue counters are zero: allocated so, and the scan kernel
+    // of the batch that used them last has reset them
+    if ((rc = ensure_zeroed(c, w.tcount, pl.tcount, gs))) return rc;
+    if ((rc = ensure(c, w.toffset, pl.toffset))) return rc;
+    if ((rc = ensure(c, w.tcursor, pl.tcursor))) return rc;
+    if ((rc = ensure_zeroed(c, w.scratch, pl.flags, gs))) return rc;
+    if (!screen && (rc = ensure(c, w.queue, pl.queue))) return rc;
+    if (!screen && (rc = ensure(c, w.sq_queue, pl.sq_queue))) return rc;
+    if (!screen && (rc = ensure(c, w.sq_desc, pl.sq_desc))) return rc;
+    if (!screen && (rc = ensure(c, w.sq_tuples, pl.sq_tuples))) return rc;
+    WorkArrays wa;
+    wa.hdr = (PrimHdr *)w.hdr.p; wa.edges = (int *)w.edges.p; wa.prp = (int *)w.prp.p;
+    wa.list = (unsigned *)w.list.p; wa.tcount = (unsigned *)w.tcount.p; wa.toffset = (unsigned *)w.toffset.p;
+    wa.tcursor = (unsigned *)w.tcursor.p; wa.flags = (int *)w.scratch.p;
+    wa.queue = (uint2 *)w.queue.p; wa.sq_queue = (uint2 *)w.sq_queue.p;
+    wa.sq_desc = (int *)w.sq_desc.p; wa.sq_tuples = (int *)w.sq_tuples.p;
+    rc = issue_batch(c, wa, pl, gs, rs, c->pipelined ? w.geom_done : nullptr, c->pipelined ? w.raster_done : nullptr, true,
+                     screen, dim, m, d_verts, nv, d_polys, d_aux, np, d_pv, npv, render_type, log_focus, force_linear);
+    if (rc) return rc;
     if (c->pipelined) w.in_use = true;
     c->last_set = set;
-    c->batch_no++;
-    if (c->profiling && (c->batch_no - 1) % c->profile_every == 0) c->timed_batches++;
-
-    c->clear_pending = false;
-    c->frame_defined = true;
-    c->drawn_since_clear = true;
-    c->polys_in += (uint64_t)np;
     return LT_OK;
 }
 
@@ -475,7 +578,7 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
         return fail(nullptr, LT_ERR_HIP, "lt_ctx_create: no HIP device (%s)", hipGetErrorString(e));
-    if (device < 0 || device >= ndev) return fail(nullptr, LT_ERR_ARG, "lt_ctx_create: device %d of %d", device, ndev);
+    if (device < 0 || device >= ndev || device >= MAX_DEVICES) return fail(nullptr, LT_ERR_ARG, "lt_ctx_create: device %d of %d", device, ndev);
     lt_ctx *c = new lt_ctx();
     c->device = device;
     c->W = width; c->H = height;
@@ -494,6 +597,7 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
         }                                                                                                 \
     } while (0)
     CREATECHK(hipSetDevice(device));
+    CREATECHK(noalloc_init(device));
     CREATECHK(hipMalloc((void **)&c->own_cbuf, n * sizeof(int)));
     CREATECHK(hipMalloc((void **)&c->own_zbuf, n * sizeof(int)));
     c->cbuf = c->own_cbuf; c->zbuf = c->own_zbuf;
@@ -1008,6 +1112,73 @@ int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts,
     if (render_type == LT_WIRE) return run_wire(c, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts, npv, log_focus, max_edges);
     return run_batch(c, false, dim, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts, npv, render_type,
                      log_focus, force_linear, max_edges);
+}
+
+int lt_submit_object_dev_noalloc(lt_ctx *c, const int32_t m[12], const int32_t *d_verts, int nv, const int32_t *d_polys,
+                                 const int32_t *d_polyaux, int np, const int32_t *d_polyverts, int npv, int render_type,
+                                 int log_focus, int force_linear, int max_edges)
+{
+    if (!c) return LT_ERR_ARG;
+    int dim = 0, rc;
+    if (render_type == LT_WIRE) return fail(c, LT_ERR_ARG, "lt_submit_object_dev_noalloc: LT_WIRE is not supported (use lt_submit_object_dev)");
+    if ((rc = check_type(c, render_type, &dim))) return rc;
+    if (np < 0 || nv < 0 || npv < 0) return fail(c, LT_ERR_ARG, "lt_submit_object_dev_noalloc: negative count");
+    if (np == 0) return LT_OK;
+    if (!d_verts || !d_polys || !d_polyverts) return fail(c, LT_ERR_ARG, "lt_submit_object_dev_noalloc: NULL array");
+    if (render_type == LT_FLAT && !d_polyaux) return fail(c, LT_ERR_ARG, "lt_submit_object_dev_noalloc: LT_FLAT needs polyaux (m_red, m_green, m_blue)");
+    if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_submit_object_dev_noalloc: log_focus %d outside 0..30", log_focus);
+    if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
+    if ((rc = use_device(c))) return rc;
+    NoAllocDevice &dev = g_noalloc[c->device];
+    if (!dev.ptr) return fail(c, LT_ERR_HIP, "lt_submit_object_dev_noalloc: the static work array has no address on device %d", c->device);
+
+    // carve the work arrays out of the static array, 256 bytes apart at least
+    const BatchPlan pl = plan_batch(c, false, dim, np, max_edges, 1u << 16);
+    WorkArrays wa;
+    size_t used = 0;
+    unsigned char *base = (unsigned char *)dev.ptr;
+    auto take = [&](size_t bytes) { void *p = base + used; used += (bytes + 255) & ~(size_t)255; return p; };
+    // the arrays that must start at zero come first, so one fill covers both
+    wa.flags = (int *)take(pl.flags);
+    wa.tcount = (unsigned *)take(pl.tcount);
+    const size_t zeroed = used;
+    wa.toffset = (unsigned *)take(pl.toffset);
+    wa.tcursor = (unsigned *)take(pl.tcursor);
+    wa.hdr = (PrimHdr *)take(pl.hdr);
+    wa.edges = (int *)take(pl.edges);
+    wa.list = (unsigned *)take(pl.list);
+    if (pl.want_prp) wa.prp = (int *)take(pl.prp);
+    wa.queue = (uint2 *)take(pl.queue);
+    wa.sq_queue = (uint2 *)take(pl.sq_queue);
+    wa.sq_desc = (int *)take(pl.sq_desc);
+    wa.sq_tuples = (int *)take(pl.sq_tuples);
+    if (used > (size_t)LT_NOALLOC_SCRATCH_BYTES)
+        return fail(c, LT_ERR_CAPACITY,
+                    "lt_submit_object_dev_noalloc: %d polygons (max_edges %d, %d x %d screen, %llu list entries) need %zu bytes of "
+                    "work arrays, the static array holds %zu: submit fewer polygons per call, lower max_edges or "
+                    "lt_set_list_capacity, or use lt_submit_object_dev",
+                    np, pl.max_edges, c->W, c->H, (unsigned long long)pl.capacity, used, (size_t)LT_NOALLOC_SCRATCH_BYTES);
+
+    // Every kernel of the batch goes on the stream of the current frame's fills: after the
+    // fills submitted before it, before those submitted after it.
+    hipStream_t s = c->rs;
+    if (c->pipelined && hipStreamQuery(c->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));       // the inputs may come from the caller's stream
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_fork, 0));
+    }
+    // the array is shared by every call on this GPU: wait for the batch that used it last
+    // (it may be on the other frame's stream, or another context's)
+    if (dev.pending) HIPCHK(c, hipStreamWaitEvent(s, dev.done, 0));
+    HIPCHK(c, hipMemsetAsync(base, 0, zeroed, s));              // order flag, sub-queue counters, tile counts
+    rc = issue_batch(c, wa, pl, s, s, nullptr, nullptr, false, false, dim, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts,
+                     npv, render_type, log_focus, force_linear);
+    // recorded even after a failed launch: what was issued before the failure still uses the array
+    hipError_t e = hipEventRecord(dev.done, s);
+    dev.pending = true;
+    if (rc) return rc;
+    HIPCHK(c, e);
+    return LT_OK;
 }
 
 int lt_submit_object(lt_ctx *c, const int32_t m[12], const int32_t *verts, int nv, const int32_t *polys,

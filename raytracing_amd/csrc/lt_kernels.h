@@ -44,6 +44,7 @@ constexpr int PRP_INTS = 12;
 // the host sums the slots.
 constexpr int BIN_MAX_TILES = 8192;        // LDS histogram limit of the binning kernels; larger screens use direct atomics
 constexpr int STATUS_SLOTS = 256;
+constexpr int MAX_DEVICES = 64;            // device indices the library keeps per-device state for
 constexpr int QUEUES = 64;                 // sub-queues between the fast and the general setup kernel
 constexpr int QUEUE_COUNT_STRIDE = 32;     // words between their counters (one 128-byte line each)
 constexpr int SETUP_FAST_THREADS = 256;
@@ -150,7 +151,7 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tile
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
                     unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done);
 void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop);
-hipError_t launch_ordered(hipStream_t s, const RasterArgs &a);   // textured batches only
+hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device);   // textured batches only; `device` is current
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 
 }  // namespace lt

@@ -13,6 +13,7 @@
 #include "lt_kernels.h"
 #include <limits.h>
 #include <algorithm>
+#include <atomic>
 
 namespace lt {
 
@@ -2132,15 +2133,17 @@ int ordered_band_rows(int W, int H)
     return r;
 }
 
-hipError_t launch_ordered(hipStream_t s, const RasterArgs &a)
+hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device)
 {
     const int R = ordered_band_rows(a.W, a.H);
     const size_t lds = (size_t)R * a.W * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the attribute belongs to the function on one device: once per device (which is current)
+    static std::atomic<bool> attr_set[MAX_DEVICES];
+    if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!attr_set[device].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute((const void *)ordered_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[device].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((ordered_kernel<6>), dim3((a.H + R - 1) / R), dim3(256), lds, s, a, R);
     return hipSuccess;

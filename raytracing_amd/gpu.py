@@ -219,6 +219,14 @@ class Context:
                                               _dp(d_polyaux), d_polys.shape[0], _dp(d_polyverts),
                                               d_polyverts.shape[0], render_type, log_focus, force_linear, max_edges))
 
+    def submit_object_dev_noalloc(self, d_verts, d_polys, d_polyverts, render_type, log_focus, d_polyaux=None,
+                                  matrix=None, force_linear=0, max_edges=0):
+        """submit_object_dev through the static work array: no device allocation in the call"""
+        m = _i32(IDENTITY if matrix is None else matrix)
+        self._chk(self.L.lt_submit_object_dev_noalloc(self.h_ctx, _p(m), _dp(d_verts), d_verts.shape[0], _dp(d_polys),
+                                                      _dp(d_polyaux), d_polys.shape[0], _dp(d_polyverts),
+                                                      d_polyverts.shape[0], render_type, log_focus, force_linear, max_edges))
+
     def submit_scene(self, sc: Scene):
         for h, (tex, lg) in enumerate(sc.textures):
             self.texture_upload(h, tex, lg)
