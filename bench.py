@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the polygon rasterization path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--workload c2-small|c2-large|c3-lin|c5]
+  python bench.py --gpus N --steps K --warmup W [--workload c2-small|c2-large|c3|c3-q2|c3-lin|c4|c5]
                   [--split frames|bands]
+
+With --gpus N > 1 and no launcher around it (WORLD_SIZE unset) the script starts its own N
+ranks through torch.distributed.run before anything touches a GPU, and passes their output on.
 
 One step = one frame: clear + one object of `--tris` synthetic triangles (transform,
 setup, binning, Z-buffered fill), inputs resident in HBM before the timed region.  With
@@ -18,19 +21,16 @@ algorithmic bytes of one frame (160 B per triangle + 8 B per pixel) over that ke
 mean duration from HIP events recorded on the library's stream.  `cpu_baseline` times
 the checker on this host's cores: the reference's own code when its prebuilt checker
 library for this screen size travelled with the tree, else the C restatement.
-`large_class` (default workload, one GPU) adds the metric's second triangle class, a few
-C2-large frames drawn after the headline measurement.
+`large_class` (default workload) adds the metric's second triangle class, a few C2-large
+frames drawn after the headline measurement; `c4` a run of the animated batch (per-frame
+matrix); `c3_4k` (one GPU) the 4K textured, clipped workload and its draw-order variant;
+`default_hw_queues` the headline step with HIP's default of four hardware queues.
 """
-import os
-
-# HIP gives a process GPU_MAX_HW_QUEUES hardware queues (4 unless set) and lets streams share
-# them; the library keeps two frames in flight on four streams of its own beside the caller's,
-# and two of them sharing one queue run one after the other.  Read when HIP starts: set first.
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
-
 import argparse
 import json
+import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,6 +50,17 @@ def make_scene(workload, tris):
         return S.gen_c2(tris, 1920, 1080, 10, radius=8)
     if workload == "c2-large":
         return S.gen_c2(tris, 1920, 1080, 10, radius=128)
+    if workload == "c4":
+        # the animated batch draws the C2-small object under a per-frame matrix (see c4_matrix)
+        return S.gen_c2(tris, 1920, 1080, 10, radius=8)
+    if workload == "c3":
+        # ~1/3 of the triangles meet a screen border or the near plane, 10 % take the perspective
+        # mapper, one light value per triangle; the few random texture mappings per million on
+        # which the reference itself divides by zero (TransBs.cpp:505) are replaced
+        return S.gen_c3(tris, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=90, regular_mapping=True)
+    if workload == "c3-q2":
+        # the same with differing vertex lights: light depends on each row's draw history
+        return S.gen_c3(tris, 3840, 2160, 11, radius=8, equal_lights=False, lin_percent=90, regular_mapping=True)
     if workload == "c3-lin":
         return S.gen_c3(tris, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=100, regular_mapping=True)
     if workload == "c5":
@@ -267,13 +278,134 @@ def bench_shade(args, rank, local_rank, world):
         print(json.dumps(out), flush=True)
 
 
+def side_frames(ctx, torch, dist, world, dev, submit, frames, warm=2):
+    """`frames` calls of submit(k) between two flushes, bracketed like the headline region
+    (barrier + device synchronisation on both sides, max over ranks) -> seconds, fragments"""
+    for k in range(warm):
+        submit(k)
+    try:
+        ctx.flush()
+    except Exception:            # reported by the caller from the counters
+        pass
+    ctx.reset_counters()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(frames):
+        submit(k)
+    err = None
+    try:
+        ctx.flush()
+    except Exception as e:
+        err = str(e)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    n = ctx.counters()
+    fr = torch.tensor([n["fragments"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fr)
+    return float(t.item()), int(fr.item()), n, err
+
+
+def c4_matrix(f):
+    """placement of frame f of the animated batch: T_set_self_rotation(f, 2f, 3f) and
+    T_cancatinate_self_world with translation (0, 0, 2048) under an identity camera
+    (reference EngPoly.cpp:510-512)"""
+    from raytracing_amd import frames as F
+    return F.frame_matrix(f)
+
+
+def c4_side(ctx, torch, dist, rank, world, dev, d_verts, d_polys, d_pv, sc, frames_per_rank=48):
+    """configuration 4 beside the headline: this rank's share of the 1024-frame animated
+    batch (frames rank, rank + world, ...), the first `frames_per_rank` of them"""
+    from raytracing_amd import frames as F
+    mine = list(F.frames_for_rank(1024, rank, world))[:frames_per_rank]
+    mats = [c4_matrix(f) for f in mine]
+
+    def submit(k):
+        ctx.clear(0)
+        ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, matrix=mats[k % len(mats)], max_edges=3)
+
+    dt, frags, _, _ = side_frames(ctx, torch, dist, world, dev, submit, len(mine))
+    total = len(mine) * world
+    return {"workload": f"c4: frames f = rank, rank + {world}, ... of the 1024-frame animated batch ({sc.n_polys} triangles at "
+                        f"{sc.width}x{sc.height}, object angles (f, 2f, 3f) & 255, translation (0, 0, 2048), clear per frame)",
+            "frames": total, "ms_per_frame_per_gpu": round(dt / len(mine) * 1e3, 4),
+            "mtris_per_s": round(sc.n_polys * total / dt / 1e6, 3), "mfragments_per_s": round(frags / dt / 1e6, 3)}
+
+
+def c3_side(torch, dist, dev, local_rank, tris, q2_tris, frames=4):
+    """the 4K workload beside the headline (one GPU): configuration 3, and its variant with
+    differing vertex lights (filled in draw order)"""
+    from raytracing_amd import gpu as G
+    out = {}
+    for name, n, nf in (("c3", tris, frames), ("c3-q2", q2_tris, 2)):
+        sc = make_scene(name, n)
+        ctx = G.Context(sc.width, sc.height, device=local_rank)
+        for h, (tex, lg) in enumerate(sc.textures):
+            ctx.texture_upload(h, tex, lg)
+        d_verts, d_polys, d_pv, d_aux = (torch.from_numpy(a).to(dev) for a in (sc.verts, sc.polys, sc.polyverts, sc.polyaux))
+
+        def submit(k):
+            ctx.clear(0)
+            ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux, matrix=sc.matrix,
+                                  force_linear=sc.force_linear, max_edges=3)
+
+        dt, frags, n_ctr, err = side_frames(ctx, torch, dist, 1, dev, submit, nf, warm=1)
+        out[name.replace("-", "_")] = {
+            "workload": f"{name}: {sc.n_polys} textured triangles at {sc.width}x{sc.height}, log_focus {sc.log_focus}, "
+                        + ("one light value per triangle" if name == "c3" else "differing vertex lights (draw-order fill)"),
+            "frames": nf, "ms_per_frame": round(dt / nf * 1e3, 4), "mtris_per_s": round(sc.n_polys * nf / dt / 1e6, 3),
+            "mfragments_per_s": round(frags / dt / 1e6, 3), "unsupported_polys": n_ctr["unsupported_polys"]}
+        if err:
+            out[name.replace("-", "_")]["flush_report"] = err[:200]
+        ctx.close()
+        del d_verts, d_polys, d_pv, d_aux, sc
+    return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks (one per GPU) through torch.distributed.run.
+    Nothing in this process has touched a GPU; the children's output passes straight through."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def default_queue_run(args):
+    """The headline step once more in a child process that keeps HIP's default of four hardware
+    queues (started and finished before this process touches the GPU) -> dict or None"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(min(args.steps, 60)), "--warmup", str(args.warmup),
+           "--workload", args.workload, "--tris", str(args.tris), "--hw-queues", "4", "--headline-only"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        return {"hw_queues": 4, "steps": j["steps"], "ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"]}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2-small")
-    ap.add_argument("--tris", type=int, default=1_000_000)
+    ap.add_argument("--tris", type=int, default=0, help="triangles per frame (0: the configuration's own: 1M, 10M for c3*)")
     ap.add_argument("--split", default="frames", choices=["frames", "bands"])
     ap.add_argument("--no-pipelining", action="store_true", help="issue every kernel on one stream")
     ap.add_argument("--host-arrays", action="store_true",
@@ -288,18 +420,39 @@ def main():
     ap.add_argument("--no-alone-pass", action="store_true", help="skip the one-stream frames that time the slowest kernel alone")
     ap.add_argument("--no-large-class", action="store_true", help="skip the C2-large frames after the headline measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
+    ap.add_argument("--no-side-lines", action="store_true", help="skip the c4 / c3_4k / default_hw_queues measurements")
+    ap.add_argument("--headline-only", action="store_true", help="the timed region and nothing else")
+    ap.add_argument("--hw-queues", type=int, default=8,
+                    help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4; the library keeps four streams busy)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_alone_pass = args.no_large_class = args.no_cpu = args.no_side_lines = True
+    if args.tris <= 0:
+        args.tris = 10_000_000 if args.workload.startswith("c3") else 1_000_000
 
+    # HIP gives a process GPU_MAX_HW_QUEUES hardware queues (4 unless set) and lets streams share
+    # them; the library keeps two frames in flight on four streams of its own beside the caller's,
+    # and two of them sharing one queue run one after the other.  Read when HIP starts: set first.
+    if not 1 <= args.hw_queues <= 32:
+        raise SystemExit("--hw-queues outside 1..32")
+    os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = 0 if "--share-gpu" in sys.argv else int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
 
-    # the all-cores CPU baseline starts child processes: before this process touches the GPU
-    all_cores = None
+    # child processes start before this process touches the GPU: the all-cores CPU baseline and
+    # the default-queue run
+    all_cores = dflt_q = None
+    headline = args.workload == "c2-small" and not args.host_arrays and args.split == "frames" and not args.no_pipelining
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_cores > 1 and args.workload.startswith("c2"):
         all_cores = cpu_all_cores(args.workload, args.tris, args.cpu_cores)
+    if rank == 0 and world == 1 and headline and not args.no_side_lines and args.hw_queues != 4:
+        dflt_q = default_queue_run(args)
 
     import torch
     import torch.distributed as dist
@@ -311,6 +464,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        observed_world = dist.get_world_size()
+        if observed_world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {observed_world} ranks")
+    else:
+        observed_world = 1
 
     if args.workload == "shade":
         bench_shade(args, rank, local_rank, world)
@@ -345,15 +503,28 @@ def main():
         if y0 < y1:
             ctx.set_band(y0, y1)
 
+    # configuration 4: this rank's frames of the 1024-frame animated batch, each under its own
+    # matrix (T_set_self_rotation + T_cancatinate_self_world are a few dozen host multiplies)
+    animated = args.workload == "c4"
+    if animated:
+        from raytracing_amd import frames as F
+        my_frames = list(F.frames_for_rank(1024, rank, world))
+        mats = [c4_matrix(f) for f in my_frames]
+    frame_no = [0]
+
     def step():
+        m = sc.matrix
+        if animated:
+            m = mats[frame_no[0] % len(mats)]
+            frame_no[0] += 1
         if args.host_arrays:
             ctx.clear(0)
             ctx.submit_object(sc.verts, sc.polys, sc.polyverts, sc.render_type, sc.log_focus, polyaux=sc.polyaux,
-                              matrix=sc.matrix, force_linear=sc.force_linear, max_edges=3)
+                              matrix=m, force_linear=sc.force_linear, max_edges=3)
         elif not bands or y0 < y1:
             ctx.clear(0)
             ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux,
-                                  matrix=sc.matrix, force_linear=sc.force_linear, max_edges=3)
+                                  matrix=m, force_linear=sc.force_linear, max_edges=3)
         if bands and world > 1:
             ctx.flush()                          # the band is complete before it is sent
             B.gather_bands([f_c, f_z], rank, world, sc.height)
@@ -368,6 +539,7 @@ def main():
     warm_stages, warm_submits = ctx.stage_ms()
     dom = max(warm_stages, key=lambda k: warm_stages[k]) if warm_submits else "fill"
     ctx.reset_counters()
+    frame_no[0] = 0
     # ... and only around every fourth launch of it: an event holds its stream for a few
     # microseconds, which two-stream frames of under 0.2 ms feel
     sample_every = 4 if args.steps >= 8 else 1
@@ -396,9 +568,11 @@ def main():
 
     stages, submits = ctx.stage_ms()
     counters = ctx.counters()
-    # the same kernel with the chip to itself: a few frames on one stream, after the timed region
+    # The same kernel with the chip to itself: a few frames on one stream right after the timed
+    # region, HIP events on the kernel's own dispatch.  (In the region two frames are in flight:
+    # two launches of the kernel share the chip and each lasts longer than a step.)
     alone_ms = None
-    if rank == 0 and not args.no_pipelining and not bands and not args.host_arrays and not args.no_alone_pass:
+    if rank == 0 and not args.no_pipelining and not bands and not args.host_arrays and not args.no_alone_pass and not animated:
         ctx.set_pipelining(False)
         ctx.set_profiling(dom, every=1)
         for _ in range(10):
@@ -414,12 +588,33 @@ def main():
         dist.all_reduce(frags)                  # bands: the frame's total; frames: all ranks' frames
     frags = int(frags.item())
 
+    # side measurements on every rank (they synchronise the ranks like the headline region)
+    side = {}
+    if headline and not args.no_large_class:
+        side["large_class"] = large_class(ctx, torch, dev, args.tris)
+    if headline and not args.no_side_lines:
+        side["c4"] = c4_side(ctx, torch, dist, rank, world, dev, d_verts, d_polys, d_pv, sc)
+
     if rank == 0:
         total_tris = sc.n_polys * args.steps * (1 if bands else world)
         frame_bytes = BYTES_PER_TRI * sc.n_polys + BYTES_PER_PIXEL * sc.width * sc.height
-        dom_ms = stages[dom] / max(submits, 1)
-        achieved = frame_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        step_ms = dt_max / args.steps * 1e3
+        in_region_ms = stages[dom] / max(submits, 1)
+        # The kernel's own compulsory bytes per launch.  Set-up reads the inputs (160 B a
+        # triangle) once and writes a record per polygon that reaches the fill; the fill reads
+        # each such record once (64 / 160 / 208 B: flat / Gouraud / textured), one 4-byte list
+        # entry per (polygon, tile) pair, and writes the frame once.
+        per_frame = max(args.steps, 1) * (1 if bands else 1)
+        drawn = counters["polys_drawn"] // per_frame
+        refs = counters["tile_refs"] // per_frame
+        rec_bytes = {2: 64, 4: 160, 8: 208}[sc.render_type]
+        own_bytes = {"fill": BYTES_PER_PIXEL * sc.width * sc.height + rec_bytes * drawn + 4 * refs,
+                     "setup": BYTES_PER_TRI * sc.n_polys + (rec_bytes + 16) * drawn,
+                     "bin": 16 * sc.n_polys + 4 * refs, "scan": 16 * sc.n_polys}.get(dom, frame_bytes)
+        kernel_ms = alone_ms if alone_ms else in_region_ms
+        achieved = own_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic, traffic_note = measured_traffic(args.workload, sc.n_polys, dom)
+        what = "Gouraud Z-buffered" if sc.render_type == 4 else ("textured" if sc.render_type == 8 else "flat")
         out = {
             "metric": "Z-tested shaded Mfragments/s + Mtris/s at 1080p/4K, 1/2/4/8 MI355X",
             "value": round(total_tris / dt_max / 1e6, 3),
@@ -427,53 +622,70 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+            "ms_per_step": round(step_ms, 4),
             "higher_is_better": True,
             "scaling": "strong" if bands else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic" + (", submitted from host memory every frame (PCIe-inclusive)" if args.host_arrays else ""),
-            "config": {"workload": f"{args.workload}: {sc.n_polys} Gouraud Z-buffered triangles per frame at "
-                                   f"{sc.width}x{sc.height}, one frame per step per GPU"
-                       if sc.render_type == 4 else
-                       f"{args.workload}: {sc.n_polys} textured triangles per frame at {sc.width}x{sc.height}",
+            "config": {"workload": f"{args.workload}: {sc.n_polys} {what} triangles per frame at {sc.width}x{sc.height}, one frame per "
+                                   f"step per GPU" + (", per-frame object matrix (frames rank, rank + world, ... of 1024)" if animated else ""),
                        "parallelism": (f"sort-first row bands x{world}, bands gathered to rank 0" if bands
-                                       else f"frame-parallel x{world}"), "tile": "64x32 or 128x32, chosen by the library"},
+                                       else f"frame-parallel x{world}"), "tile": "64x32 or 128x32, chosen by the library",
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "world_size_observed": observed_world,
+                       "backend": (args.backend if world > 1 else None)},
             "mfragments_per_s": round(frags / dt_max / 1e6, 3),
             "fragments_per_frame": frags // max(args.steps, 1) // (1 if bands else world),
             "stage_ms_per_frame": {k: round(v / max(warm_submits, 1), 4) for k, v in warm_stages.items()},
-            "stage_ms_measured_on": f"{warm_submits} warm-up frame(s), all stages timed; roofline.kernel is timed "
-                                    f"on {submits} of the {args.steps} measured frames (every {sample_every}th)",
+            "stage_ms_measured_on": f"{warm_submits} warm-up frame(s), all stages timed",
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_note": traffic_note,
-                         "kernel_ms": round(dom_ms, 4),
-                         "algorithmic_bytes_per_launch": frame_bytes,
-                         "whole_step_frac": round(frame_bytes / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
+                         "kernel_ms": round(kernel_ms, 4),
+                         "kernel_ms_measured_on": ("10 frames on one stream right after the timed region, HIP events on the kernel's own "
+                                                   "dispatch (the kernel with the chip to itself)" if alone_ms else
+                                                   f"{submits} of the {args.steps} measured frames (every {sample_every}th)"),
+                         "algorithmic_bytes_per_launch": own_bytes,
+                         "algorithmic_bytes_are": "this kernel's compulsory traffic: the frame written once, one record per polygon that "
+                                                  "reaches the fill, one list entry per (polygon, tile) pair" if dom == "fill" else
+                                                  "this kernel's compulsory traffic",
+                         "path_bytes_per_step": frame_bytes,
+                         "whole_step_frac": round(frame_bytes / (dt_max / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
+                         "in_region": {"kernel_ms": round(in_region_ms, 4), "launches_timed": submits,
+                                       "note": "two frames are in flight in the timed region: two launches of the kernel share the "
+                                               "chip, so one launch lasts longer than a step"}},
         }
-        if alone_ms:
-            # in the timed region two frames are in flight, so two launches of the kernel share the
-            # chip and each takes about twice as long as it does alone
-            out["roofline"]["alone"] = {"kernel_ms": round(alone_ms, 4), "achieved": round(frame_bytes / (alone_ms * 1e-3) / 1e9, 2),
-                                        "frac": round(frame_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                                        "measured_on": "10 frames on one stream after the timed region"}
-            out["roofline"]["note"] = ("kernel_ms is one launch in the timed region, where two frames are in flight and two launches "
-                                       "of this kernel share the chip; `alone` is the same kernel with the chip to itself")
-        out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
-        vr = valu_roofline(args.workload, sc.n_polys, dom, dom_ms)
+        vr = valu_roofline(args.workload, sc.n_polys, dom, kernel_ms)
         if vr:
             out["roofline_valu"] = vr
-        if not args.no_cpu and world == 1:          # the CPU legs run beside the one-GPU line only
+        if dflt_q:
+            out["default_hw_queues"] = dflt_q
+        out.update(side)
+        print_line = out
+    else:
+        print_line = None
+
+    # one GPU: the 4K workload and the CPU legs beside the headline
+    if rank == 0 and world == 1:
+        if not args.no_cpu:
             base, oc, oz = cpu_baseline(sc, passes=2 if sc.n_polys <= 2_000_000 else 1)
-            c, z = ctx.readback()
-            out["cpu_baseline"] = base
-            out["cpu_baseline_touched_rows"] = cpu_touched_rows(sc)
+            # the frame the CPU leg drew (the side measurements have drawn other frames since)
+            ctx.clear(0)
+            ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux, matrix=sc.matrix,
+                                  force_linear=sc.force_linear, max_edges=3)
+            c, z = ctx.readback(check=False)
+            print_line["cpu_baseline"] = base
+            print_line["cpu_baseline_touched_rows"] = cpu_touched_rows(sc)
             if all_cores:
-                out["cpu_baseline_all_cores"] = all_cores
-            out["frame_matches_cpu"] = bool(np.array_equal(c, oc) and np.array_equal(z, oz))
-        if args.workload == "c2-small" and world == 1 and not args.no_large_class and not args.host_arrays:
-            out["large_class"] = large_class(ctx, torch, dev, args.tris)
-        print(json.dumps(out), flush=True)
+                print_line["cpu_baseline_all_cores"] = all_cores
+            print_line["frame_matches_cpu"] = bool(np.array_equal(c, oc) and np.array_equal(z, oz))
+        if headline and not args.no_side_lines:
+            ctx.close()
+            del d_verts, d_polys, d_pv
+            print_line["c3_4k"] = c3_side(torch, dist, dev, local_rank, 10_000_000, 1_000_000)
+    if rank == 0:
+        assert print_line["n_gpus"] == args.gpus
+        print(json.dumps(print_line), flush=True)
 
     if world > 1:
         dist.barrier()
