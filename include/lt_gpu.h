@@ -316,6 +316,21 @@ int lt_submit_object_dev_noalloc(lt_ctx *ctx, const int32_t m[12],
 int lt_submit_screen_polys(lt_ctx *ctx, int kind, const int32_t *tuples, int ntuples,
                            const int32_t *desc, int n, int max_edges);
 
+/* G_prp_textured_polygon (Graphics.h:108-113, GraphicsPoly.cpp:520-684) for n already-projected
+ * closed polygons in array order: tuples of dim 8 (X Y Z' R G B Tx Ty; the edge scan
+ * interpolates Z' R G B only, GraphicsPoly.cpp:559), desc[i] = {first tuple, length (edges),
+ * unused, texture handle}, and per polygon the function's other arguments
+ *   prp[i][12] = {O[0], O[1], O[2], O[6], O[7], u[0], u[1], u[2], v[0], v[1], v[2],
+ *                 log_texture_scale}
+ * -- O is the view-space tuple the texture origin maps to (X Y Z and its texture coordinates,
+ * 16.16), u and v the texture orientation vectors of MI_tmapping_vectors (EngBase.cpp:145-179).
+ * log_focus is M_camera_log_focus, which the reference's function reads as a global
+ * (GraphicsPoly.cpp:614-633).  Texture coordinates are exact every 32 pixels of a span
+ * (G_LINEAR, GraphicsPoly.cpp:40) and linear between; where the divisor zz is 0 the reference
+ * uses 0 for both.  HOST pointers. */
+int lt_submit_screen_polys_prp(lt_ctx *ctx, const int32_t *tuples, int ntuples, const int32_t *desc,
+                               const int32_t *prp, int n, int log_focus, int max_edges);
+
 #ifdef __cplusplus
 }
 #endif

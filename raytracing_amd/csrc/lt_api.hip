@@ -109,7 +109,7 @@ struct lt_ctx {
     hipStream_t own_gs = nullptr, own_gs2 = nullptr, own_rs = nullptr;    // internal streams (non-blocking)
     hipStream_t gs = nullptr, rs = nullptr;            // streams in use: own_* or `stream`
     hipEvent_t ev_fork = nullptr;
-    DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn;      // staging for host-pointer calls
+    DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn, s_prp;      // staging for host-pointer calls
     DevBuf line_winner, line_colours, s_lines;   // wireframe: per-pixel winning line, per-polygon colour, staged lines
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
@@ -284,7 +284,7 @@ struct WorkArrays {
     int *sq_desc = nullptr, *sq_tuples = nullptr;
 };
 
-BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edges, uint64_t min_capacity)
+BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edges, uint64_t min_capacity, bool screen_prp = false)
 {
     BatchPlan p;
     const int na = dim - 2;
@@ -295,7 +295,7 @@ BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edge
     p.capacity = c->list_capacity_user ? c->list_capacity_user : (uint64_t)np * 64u;
     if (p.capacity < min_capacity) p.capacity = min_capacity;
     p.qcap = setup_queue_cap(np);
-    p.want_prp = !screen && dim == 8;
+    p.want_prp = (!screen && dim == 8) || screen_prp;
     p.hdr = (size_t)np * sizeof(PrimHdr);
     // one record (header copy + edges 0..2) per slot, then the planes of edges 3 and up
     p.edges = (size_t)np * (16 + (p.emax < 3 ? 3 : p.emax) * edge_ints(na) * sizeof(int));
@@ -321,7 +321,7 @@ BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edge
 int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_t gs, hipStream_t rs, hipEvent_t geom_done,
                 hipEvent_t raster_done, bool timing, bool screen, int dim, const int32_t *m, const int *d_verts, int nv,
                 const int *d_polys, const int *d_aux, int np, const int *d_pv, int npv, int render_type, int log_focus,
-                int force_linear)
+                int force_linear, const int *d_prp_src = nullptr)
 {
     const int na = dim - 2;
     const int emax = pl.emax;
@@ -354,7 +354,10 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
     sa.tile_w_log = twl;
     sa.emax = emax;
     sa.hdr = wa.hdr; sa.edges = wa.edges;
-    sa.prp = want_prp ? wa.prp : nullptr;
+    sa.prp = want_prp && !screen ? wa.prp : nullptr;
+    // screen-level perspective mapper: the caller's constants become this batch's (slot = polygon)
+    if (d_prp_src) HIPCHK(c, hipMemcpyAsync(wa.prp, d_prp_src, (size_t)np * PRP_INTS * sizeof(int), hipMemcpyDeviceToDevice, gs));
+    sa.prp_given = d_prp_src ? 1 : 0;
     sa.order_flag = order_flag; sa.order_gen = order_gen; sa.detect_order = (dim == 8 && c->order_mode == LT_ORDER_AUTO) ? 1 : 0;
     // object batches: unclipped triangles take the fast kernel, the rest go through sub-queues
     sa.queue = screen ? nullptr : wa.queue;
@@ -439,9 +442,10 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
 
 // One batch through a work set of the context (grown on demand).
 int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_verts, int nv, const int *d_polys, const int *d_aux,
-              int np, const int *d_pv, int npv, int render_type, int log_focus, int force_linear, int max_edges)
+              int np, const int *d_pv, int npv, int render_type, int log_focus, int force_linear, int max_edges,
+              const int *d_prp_src = nullptr)
 {
-    const BatchPlan pl = plan_batch(c, screen, dim, np, max_edges, 1u << 20);
+    const BatchPlan pl = plan_batch(c, screen, dim, np, max_edges, 1u << 20, d_prp_src != nullptr);
     int rc;
     // batches whose work arrays stay small take four sets and both geometry streams in turns
     const bool deep = c->pipelined && np <= (1 << 21) && pl.capacity <= (1ull << 27);
@@ -485,7 +489,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     wa.queue = (uint2 *)w.queue.p; wa.sq_queue = (uint2 *)w.sq_queue.p;
     wa.sq_desc = (int *)w.sq_desc.p; wa.sq_tuples = (int *)w.sq_tuples.p;
     rc = issue_batch(c, wa, pl, gs, rs, c->pipelined ? w.geom_done : nullptr, c->pipelined ? w.raster_done : nullptr, true,
-                     screen, dim, m, d_verts, nv, d_polys, d_aux, np, d_pv, npv, render_type, log_focus, force_linear);
+                     screen, dim, m, d_verts, nv, d_polys, d_aux, np, d_pv, npv, render_type, log_focus, force_linear, d_prp_src);
     if (rc) return rc;
     if (c->pipelined) w.in_use = true;
     c->last_set = set;
@@ -635,7 +639,7 @@ int lt_ctx_destroy(lt_ctx *c)
     if (c->own_rs) (void)hipStreamSynchronize(c->own_rs);
     if (c->alt_rs) (void)hipStreamSynchronize(c->alt_rs);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn,
+    DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn, &c->s_prp,
                       &c->line_winner, &c->line_colours, &c->s_lines};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1230,6 +1234,58 @@ int lt_submit_screen_polys(lt_ctx *c, int kind, const int32_t *tuples, int ntupl
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return run_batch(c, true, dim, nullptr, nullptr, 0, (const int *)c->s_polys.p, nullptr, n, (const int *)c->s_pv.p, ntuples,
                      kind, 0, 0, max_edges);
+}
+
+int lt_submit_screen_polys_prp(lt_ctx *c, const int32_t *tuples, int ntuples, const int32_t *desc, const int32_t *prp, int n,
+                               int log_focus, int max_edges)
+{
+    if (!c) return LT_ERR_ARG;
+    if (n == 0) return LT_OK;
+    if (n < 0 || ntuples <= 0 || !tuples || !desc || !prp) return fail(c, LT_ERR_ARG, "lt_submit_screen_polys_prp: bad argument");
+    if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_submit_screen_polys_prp: log_focus %d outside 0..30", log_focus);
+    if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
+    int rc;
+    if ((rc = use_device(c))) return rc;
+    // descriptors with the perspective fill named in the length word; the nine coefficients of
+    // GraphicsPoly.cpp:570-578 from O, u, v in wrapping 32-bit arithmetic, as the set-up kernel
+    // makes them for object batches
+    std::vector<int32_t> d((size_t)n * 4), k((size_t)n * PRP_INTS);
+    auto wm = [](int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); };
+    auto ws = [](int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); };
+    for (int i = 0; i < n; i++) {
+        const int32_t *q = prp + (size_t)i * 12;
+        const int32_t len = desc[(size_t)i * 4 + 1];
+        if (len < 0 || len > 255) return fail(c, LT_ERR_ARG, "lt_submit_screen_polys_prp: polygon %d has %d edges", i, len);
+        if (q[11] < 0 || q[11] > 24) return fail(c, LT_ERR_ARG, "lt_submit_screen_polys_prp: polygon %d: log_texture_scale %d outside 0..24", i, q[11]);
+        d[(size_t)i * 4] = desc[(size_t)i * 4];
+        d[(size_t)i * 4 + 1] = len | (9 << 8);
+        d[(size_t)i * 4 + 2] = desc[(size_t)i * 4 + 2];
+        d[(size_t)i * 4 + 3] = desc[(size_t)i * 4 + 3];
+        const int32_t x0 = q[0], y0 = q[1], z0 = q[2], u0 = q[3], v0 = q[4];
+        const int32_t *u = q + 5, *v = q + 8;
+        int32_t *o = k.data() + (size_t)i * PRP_INTS;
+        o[0] = ws(wm(v[2], y0), wm(v[1], z0));      // ui
+        o[1] = ws(wm(v[0], z0), wm(v[2], x0));      // uj
+        o[2] = ws(wm(v[1], x0), wm(v[0], y0));      // uc
+        o[3] = ws(wm(u[1], z0), wm(u[2], y0));      // vi
+        o[4] = ws(wm(u[2], x0), wm(u[0], z0));      // vj
+        o[5] = ws(wm(u[0], y0), wm(u[1], x0));      // vc
+        o[6] = ws(wm(v[1], u[2]), wm(v[2], u[1]));  // zi
+        o[7] = ws(wm(v[2], u[0]), wm(v[0], u[2]));  // zj
+        o[8] = ws(wm(v[0], u[1]), wm(v[1], u[0]));  // zc
+        o[9] = u0; o[10] = v0; o[11] = q[11];
+    }
+    HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
+    HIPCHK(c, hipStreamSynchronize(c->own_gs2));
+    if ((rc = ensure(c, c->s_polys, (size_t)n * 16))) return rc;
+    if ((rc = ensure(c, c->s_pv, (size_t)ntuples * 8 * 4))) return rc;
+    if ((rc = ensure(c, c->s_prp, (size_t)n * PRP_INTS * 4))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_polys.p, d.data(), (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_pv.p, tuples, (size_t)ntuples * 8 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_prp.p, k.data(), (size_t)n * PRP_INTS * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return run_batch(c, true, 8, nullptr, nullptr, 0, (const int *)c->s_polys.p, nullptr, n, (const int *)c->s_pv.p, ntuples,
+                     LT_TEXTURED, log_focus, 0, max_edges, (const int *)c->s_prp.p);
 }
 
 int lt_submit_lines_dev(lt_ctx *c, const int32_t *d_lines, int n)

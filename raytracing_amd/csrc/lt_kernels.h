@@ -90,7 +90,8 @@ struct SetupArgs {
     int *order_flag;         // device word set to order_gen when a textured polygon's vertex lights differ
     int order_gen;           // this batch's number (never 0): a stale flag of an earlier batch does not count
     int detect_order;
-    int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured batches) or null
+    int *prp;                // int32[np][PRP_INTS]: perspective-mapper constants (textured object batches) or null
+    int prp_given;           // screen batches: the caller supplied the constants of every polygon (indexed by polygon)
     int band_y0, band_y1;    // rows [band_y0, band_y1) are drawn by this context (whole screen: 0, H)
     int tile_w_log;          // log2 of the tile width of this batch (6 or 7)
     int cx0, cy0, cx1, cy1;  // 2-D clip window C_x_clipping_min .. C_y_clipping_max (whole screen: 0, 0, W-1, H-1)

@@ -890,7 +890,8 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
     if (e < 2 || e + 1 > 16 || e > a.max_edges || first < 0 || (long long)first + e + 1 > (long long)a.npv) {
         bad = true; go = false;
     }
-    if (kind == KIND_TEX_LIN && (tex < 0 || tex >= 64)) { unsupported = true; go = false; }
+    if (kind >= KIND_TEX_LIN && (tex < 0 || tex >= 64)) { unsupported = true; go = false; }
+    if (SCREEN && kind == KIND_TEX_PRP && !a.prp_given) { unsupported = true; go = false; }
 
     // ---- read the polygon's tuples.  Polygons of up to PRE tuples (triangles, quads) are
     // read up front -- all records at once, then all vertices at once -- so that a lane

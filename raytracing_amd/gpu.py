@@ -249,3 +249,22 @@ class Context:
         tup = np.concatenate(chunks, axis=0) if chunks else np.zeros((0, dim), np.int32)
         self._chk(self.L.lt_submit_screen_polys(self.h_ctx, kind, _p(tup), tup.shape[0], _p(desc), len(polys),
                                                 min(me, 15)))
+
+    def submit_screen_polys_prp(self, polys, log_focus):
+        """G_prp_textured_polygon for a list of (length, tuples int32[length+1][8], O int32[8], u int32[3],
+        v int32[3], texture handle, log_texture_scale) in draw order."""
+        desc = np.zeros((len(polys), 4), np.int32)
+        prp = np.zeros((len(polys), 12), np.int32)
+        chunks, first, me = [], 0, 1
+        for i, (length, t, O, u, v, tex, log_scale) in enumerate(polys):
+            t = _i32(t).reshape(-1, 8)
+            assert t.shape[0] == length + 1
+            desc[i] = (first, length, 0, tex)
+            O = _i32(O)
+            prp[i] = (O[0], O[1], O[2], O[6], O[7], u[0], u[1], u[2], v[0], v[1], v[2], log_scale)
+            chunks.append(t)
+            first += length + 1
+            me = max(me, length)
+        tup = np.concatenate(chunks, axis=0)
+        self._chk(self.L.lt_submit_screen_polys_prp(self.h_ctx, _p(tup), tup.shape[0], _p(desc), _p(prp), len(polys),
+                                                    int(log_focus), min(me, 15)))

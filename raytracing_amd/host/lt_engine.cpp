@@ -40,6 +40,8 @@ QKind q_kind = Q_NONE;
 int q_type = 0;                                      // LT_FLAT / LT_SHADED / LT_TEXTURED
 int q_focus = 0, q_force = 0;
 std::vector<int32_t> q_tuples, q_desc;               // Q_SCREEN
+std::vector<int32_t> q_prp;                          // Q_SCREEN with the perspective mapper: 12 words a polygon
+constexpr int LT_TEXTURED_PRP = 9;                   // queue type of G_prp_textured_polygon (no C-ABI render type)
 std::vector<int32_t> q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
 std::vector<int32_t> q_lines;                        // Q_LINES: {x1 y1 z1 x2 y2 z2 lit-colour 0}
 int q_max_edges = 0;
@@ -106,7 +108,10 @@ int texture_handle(HW_pixel *texels, int log_size)
 
 void run_queue()
 {
-    if (q_kind == Q_SCREEN && !q_desc.empty()) {
+    if (q_kind == Q_SCREEN && !q_desc.empty() && q_type == LT_TEXTURED_PRP) {
+        chk(lt_submit_screen_polys_prp(g_ctx, q_tuples.data(), (int)(q_tuples.size() / 8), q_desc.data(), q_prp.data(),
+                                       (int)(q_desc.size() / 4), q_focus, q_max_edges));
+    } else if (q_kind == Q_SCREEN && !q_desc.empty()) {
         int dim = q_type == LT_FLAT ? 3 : (q_type == LT_SHADED ? 6 : 8);
         chk(lt_submit_screen_polys(g_ctx, q_type, q_tuples.data(), (int)(q_tuples.size() / dim), q_desc.data(),
                                    (int)(q_desc.size() / 4), q_max_edges));
@@ -120,13 +125,14 @@ void run_queue()
     q_kind = Q_NONE;
     g_tex_epoch++;
     q_lines.clear();
+    q_prp.clear();
     q_tuples.clear(); q_desc.clear(); q_verts.clear(); q_polys.clear(); q_aux.clear(); q_pv.clear();
     q_max_edges = 0;
 }
 
 void open_queue(QKind kind, int type)
 {
-    if (q_kind != kind || q_type != type || (kind == Q_VIEW && (q_focus != M_camera_log_focus || q_force != M_force_linear_tmapping)))
+    if (q_kind != kind || q_type != type || ((kind == Q_VIEW || type == LT_TEXTURED_PRP) && (q_focus != M_camera_log_focus || q_force != M_force_linear_tmapping)))
         run_queue();
     q_kind = kind; q_type = type; q_focus = M_camera_log_focus; q_force = M_force_linear_tmapping;
     g_host_frame_current = false;
@@ -231,6 +237,18 @@ static void queue_screen(int type, int dim, int *edges, int length, HW_pixel col
     q_desc.insert(q_desc.end(), d, d + 4);
     q_tuples.insert(q_tuples.end(), edges, edges + (length + 1) * dim);
     if (length > q_max_edges) q_max_edges = length;
+}
+
+// GraphicsPoly.cpp:520-684; M_camera_log_focus is read at the time of the call, as the
+// reference's function reads the global while it draws
+void G_prp_textured_polygon(int *edges, int length, int *O, int *u, int *v, HW_pixel *texture, int log_texture_size,
+                            int log_texture_scale)
+{
+    need_ctx();
+    const int tex = texture_handle(texture, log_texture_size);
+    queue_screen(LT_TEXTURED_PRP, G_LNG_TEXTURED, edges, length, 0, tex);
+    const int32_t k[12] = {O[0], O[1], O[2], O[6], O[7], u[0], u[1], u[2], v[0], v[1], v[2], log_texture_scale};
+    q_prp.insert(q_prp.end(), k, k + 12);
 }
 
 // GraphicsBase.cpp:165-253.  A clipped end point takes depth 0 (what the reference reads in

@@ -51,6 +51,8 @@ void G_line(int *vertex1, int *vertex2, HW_pixel colour, int red, int green, int
 void G_flat_polygon(int *edges, int length, HW_pixel colour, int red, int green, int blue);
 void G_shaded_polygon(int *edges, int length, HW_pixel colour);
 void G_lin_textured_polygon(int *edges, int length, HW_pixel *texture, int log_texture_size);
+void G_prp_textured_polygon(int *edges, int length, int *O, int *u, int *v, HW_pixel *texture, int log_texture_size,
+                            int log_texture_scale);       // Graphics.h:108-113; reads M_camera_log_focus
 
 // ---- Trans.h:27-72 (the parts on the polygon path)
 #define T_LNG_VECTOR 4

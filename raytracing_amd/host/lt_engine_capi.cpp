@@ -206,4 +206,10 @@ void lte_g_polygon(int kind, int *tuples, int length, int colour, int r, int g, 
     else G_lin_textured_polygon(tuples, length, g_texs[tex].m_texture_bytes, g_texs[tex].m_log_texture_size);
 }
 
+void lte_g_prp_polygon(int *tuples, int length, int *O, int *u, int *v, int tex, int log_scale, int log_focus)
+{
+    M_camera_log_focus = log_focus;
+    G_prp_textured_polygon(tuples, length, O, u, v, g_texs[tex].m_texture_bytes, g_texs[tex].m_log_texture_size, log_scale);
+}
+
 }  // extern "C"

@@ -13,6 +13,7 @@ and expected outputs -- stored as .npz (no pickles) and .json next to this scrip
   c1_scene.npz      configuration 1: the tracer.dat world (quad + three spheres, tessellated
                     and lit by this script) as flat scene arrays, with the reference's frame
   crops.npz         a few raw 32x32 crops of reference frames
+  prp_kats.json     frames of G_prp_textured_polygon calls (the perspective mapper at the G_* level)
   c4_frames.json    configuration 4: digests of four frames of the animated 1M-triangle batch
   c5_frame.json     configuration 5 in shape: digests of one 16384 x 16384 frame of 1M triangles
   data_kats.json    what the reference's D_data builds from the .dat files of
@@ -519,6 +520,50 @@ def bench_frame():
                 depth=S.frame_digest(z), drawn_pixels=int((z != 2 ** 31 - 1).sum()))
 
 
+def prp_cases():
+    """Frames of G_prp_textured_polygon calls at WIRE_W x WIRE_H, log_focus 7, texture
+    make_texture(9, 6): name -> list of (length, tuples int32[length+1][8], O int32[8], u int32[3],
+    v int32[3], texture handle, log_texture_scale).  O, u, v are random (the arithmetic wraps; a
+    zero divisor takes the reference's own zero branch)."""
+    cases = {}
+    for k, equal in enumerate((True, False, True)):
+        rng = S.Rng(8100 + k)
+        polys = []
+        for (e, t, col) in S.gen_screen_polys(70, WIRE_W, WIRE_H, seed=8200 + k, dim=8, max_edges=6, spread=1 + k % 2):
+            if equal:
+                t[:, 3:6] = t[0, 3:6]
+            O = np.zeros(8, np.int32)
+            O[0:2] = rng.ints(-400, 400, 2)
+            O[2] = rng.ints(20, 1500, 1)[0]
+            O[6:8] = rng.ints(0, 1023, 2) << 16
+            mag = (3, 40, 300)[k]
+            u = rng.ints(-mag, mag, 3).astype(np.int32)
+            v = rng.ints(-mag, mag, 3).astype(np.int32)
+            if int(rng.ints(0, 9, 1)[0]) == 0:
+                v = u.copy()                              # degenerate orientation: zi = zj = zc = 0
+            polys.append((e, t, O, u, v, 0, int(rng.ints(4, 9, 1)[0])))
+        cases[f"prp_{'equal' if equal else 'vary'}_{k}"] = polys
+    return cases
+
+
+def run_prp_case(polys, be):
+    """be: oracle.port.Oracle or oracle.ref.Ref of WIRE_W x WIRE_H"""
+    be.set_texture(0, S.make_texture(9, 6), 6)
+    be.clear(0x000020, 255, 255, 255)
+    for (e, t, O, u, v, tex, ls) in polys:
+        be.g_prp_polygon(t, O, u, v, tex, ls, 7)
+    return be.cbuf().copy(), be.zbuf().copy()
+
+
+def prp_kats():
+    """G_prp_textured_polygon of the reference build on prp_cases(): digests."""
+    out = {}
+    for name, polys in prp_cases().items():
+        c, z = run_prp_case(polys, R.Ref(WIRE_W, WIRE_H))
+        out[name] = dict(colour=S.frame_digest(c), depth=S.frame_digest(z), drawn=int((z != 2 ** 31 - 1).sum()))
+    return out
+
+
 C4_FRAMES = (1, 37, 100, 203)
 
 
@@ -558,6 +603,9 @@ def c5_frame():
 
 
 def main():
+    if "--prp" in sys.argv:
+        json.dump(prp_kats(), open(os.path.join(HERE, "prp_kats.json"), "w"), indent=1, sort_keys=True)
+        return
     if "--c4c5" in sys.argv:
         json.dump(c4_frames(), open(os.path.join(HERE, "c4_frames.json"), "w"), indent=1, sort_keys=True)
         json.dump(c5_frame(), open(os.path.join(HERE, "c5_frame.json"), "w"), indent=1, sort_keys=True)
@@ -568,6 +616,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "normals_kats.npz"), **normals_kats())
     json.dump(wire_kats(), open(os.path.join(HERE, "wire_kats.json"), "w"), indent=1, sort_keys=True)
     json.dump(window_kats(), open(os.path.join(HERE, "window_kats.json"), "w"), indent=1, sort_keys=True)
+    json.dump(prp_kats(), open(os.path.join(HERE, "prp_kats.json"), "w"), indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "gate_kats.npz"), **gate_kats())
     np.savez_compressed(os.path.join(HERE, "bicubic_kats.npz"), **bicubic_kats())
     if not os.path.isdir(REFDIR):
