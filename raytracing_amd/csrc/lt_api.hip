@@ -1311,7 +1311,11 @@ int lt_submit_lines(lt_ctx *c, const int32_t *lines, int n)
     if (n < 0 || !lines) return fail(c, LT_ERR_ARG, "lt_submit_lines: bad argument");
     int rc = use_device(c);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->rs));        // an earlier list may still be read
+    // an earlier list may still be read, by the line kernels of this frame or of the frame
+    // before it, which run on the other fill stream when two frames are in flight
+    HIPCHK(c, hipStreamSynchronize(c->rs));
+    if (c->own_rs && c->own_rs != c->rs) HIPCHK(c, hipStreamSynchronize(c->own_rs));
+    if (c->alt_rs && c->alt_rs != c->rs) HIPCHK(c, hipStreamSynchronize(c->alt_rs));
     if ((rc = ensure(c, c->s_lines, (size_t)n * 32))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->s_lines.p, lines, (size_t)n * 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

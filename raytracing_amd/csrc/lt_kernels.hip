@@ -1768,16 +1768,31 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
         // in issue order).
         {
             const int cnt = live ? r1 - r0 : 0;
-            int incl = cnt;
+            const bool owns = cnt > 0;
+            // The wave's polygons are taken in the order of their width inside the tile (a
+            // counting sort over 16 width classes, ballots only): a step of 64 rows lasts as
+            // long as its longest span, and rows of polygons of similar width have spans of
+            // similar length.  `rank` is a polygon's place in that order (polygons without
+            // rows come last), and rows are numbered in that order.
+            const int wdt = cx1 - cx0 + 1;
+            const int cls = !owns ? 16 : (wdt <= 16 ? (wdt - 1) >> 1 : 8 + min((wdt - 17) >> 3, 7));
+            int rank = 0, placed = 0;
+#pragma unroll
+            for (int b = 0; b <= 16; b++) {
+                const unsigned long long m = __ballot(cls == b);
+                const int within = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                rank = cls == b ? placed + within : rank;
+                placed += __popcll(m);
+            }
+            // row counts to their places, prefix sum there, each polygon fetches its own
+            int incl_s = __builtin_amdgcn_ds_permute(rank << 2, cnt);
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
-                const int o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
+                const int o = __shfl_up(incl_s, d);
+                if (lane >= d) incl_s += o;
             }
-            const int total = __shfl(incl, 63);
-            const bool owns = cnt > 0;
-            const unsigned long long owners = __ballot(owns);
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(owners >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)owners, 0u));
+            const int total = __shfl(incl_s, 63);
+            const int incl = __builtin_amdgcn_ds_bpermute(rank << 2, incl_s);
             int4 *st = stage + (size_t)(t & ~63) * 4;       // this wave's 64 x 4 pieces
             unsigned long long *mk = marks + (t >> 6) * TH;
             const int last = incl - 1;

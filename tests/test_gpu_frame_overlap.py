@@ -144,3 +144,41 @@ def test_wire_objects_over_polygons_across_frames(env):
     # reference, so the comparison with the restatement is on the depth buffer (lines never write it) and on
     # the two GPU runs above for colour
     assert np.array_equal(got[0][1], orc.zbuf())
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_host_line_lists_across_frames_without_a_flush(env, overlap):
+    """clear, polygons, host lines, clear, other host lines, ... with no flush in between: every
+    list is staged in one device array, which a later list must not overwrite while the line
+    kernels of the frame before still read it (they run on the other fill stream).  The depth
+    tests counted over all frames say whether each frame drew its own lines."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as MG
+    P, G = env
+    W, H = MG.WIRE_W, MG.WIRE_H
+    sc = S.gen_c2(3000, W, H, 7, radius=20, seed=515)
+    lists = [MG.wire_lines(600 + f, 2500 + 300 * f, 1, -2, -6200, -100) for f in range(6)]
+    # expected depth tests: polygons' fragments + one test per point of each unclipped line
+    orc = P.Oracle(W, H)
+    want = 0
+    for f, lines in enumerate(lists):
+        orc.clear(0, 0, 0, 0)
+        orc.reset_counters()
+        orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, None, sc.polyverts, sc.render_type, sc.log_focus)
+        for l in lines:
+            orc.g_line(l[0:3], l[3:6], int(l[6]), 255, 255, 255)
+        want += orc.counters()["fragments"]
+    ctx = G.Context(W, H)
+    ctx.set_frame_overlap(overlap)
+    ctx.reset_counters()
+    for f, lines in enumerate(lists):
+        ctx.clear(0)
+        ctx.submit_scene(sc)
+        l = lines.copy()
+        l[:, 6] = [P.cl_light(int(c), 255, 255, 255) for c in l[:, 6]]
+        ctx.submit_lines(l)
+    c, z = ctx.readback()
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert ctx.counters()["fragments"] == want
+    ctx.close()
