@@ -108,6 +108,14 @@ int lt_set_tile_width(lt_ctx *ctx, int width);
 #define LT_ORDER_AUTO    0
 #define LT_ORDER_ALWAYS  1
 #define LT_ORDER_NEVER   2
+/* The draw-order kernel works on bands of rows.  For batches of 20 000 polygons or more each
+ * band gets the list of its polygons in draw order first (a stable counting sort on the
+ * device), and spans of up to 16 pixels are drawn 64 at a time; smaller batches, and screens
+ * of more than 1024 bands (a band is as many rows as fit 150 KB of LDS at 8 bytes a pixel: 4
+ * rows at 3840 pixels, 1 row from 9600 pixels on), let every band read every header.  Either flag,
+ * or-ed into the mode, overrides the choice; the frame does not depend on it. */
+#define LT_ORDER_LISTS_ALWAYS 4
+#define LT_ORDER_LISTS_NEVER  8
 int lt_set_textured_order(lt_ctx *ctx, int mode);
 
 /* --- framebuffer --------------------------------------------------------------- */

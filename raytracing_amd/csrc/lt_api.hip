@@ -16,7 +16,10 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// small device scratch: order flag (first 256 bytes), then the setup sub-queue counters
+// batches of fewer polygons fill in draw order by reading every header in every band
+constexpr int BAND_LIST_MIN_POLYS = 20000;
+
+// small device scratch: order flag and the band lists' allocation word (first 256 bytes), then the setup sub-queue counters
 constexpr size_t kScratchBytes = 256 + 2 * (size_t)QUEUES * QUEUE_COUNT_STRIDE * sizeof(unsigned);
 
 struct DevBuf {
@@ -91,6 +94,7 @@ struct lt_ctx {
     uint64_t polys_in = 0;
     uint64_t list_capacity_user = 0;
     int order_mode = 0;                // LT_ORDER_AUTO / ALWAYS / NEVER
+    int order_lists = 0;               // 0: band lists for large batches; LT_ORDER_LISTS_ALWAYS / LT_ORDER_LISTS_NEVER
     // Per-batch workspace (grown on demand, reused).  The set-up and binning of a batch (which
     // do not touch the frame) run on a geometry stream while the fill of the batch before it
     // runs on `rs`.  Small batches take the sets in turns of four and the two geometry streams
@@ -99,6 +103,7 @@ struct lt_ctx {
     // arrays are large stay with two sets and one geometry stream.
     struct Work {
         DevBuf hdr, edges, prp, list, tcount, toffset, tcursor, queue, scratch;   // scratch: order flag + sub-queue counters
+        DevBuf bcnt, bplace, blist;                                               // band lists of the draw-order fill
         DevBuf sq_desc, sq_tuples, sq_queue;                                      // screen queue of the fast set-up kernel
         hipEvent_t geom_done = nullptr, raster_done = nullptr;
         bool in_use = false;
@@ -272,6 +277,10 @@ struct BatchPlan {
     bool want_prp = false;
     size_t hdr = 0, edges = 0, list = 0, prp = 0, tcount = 0, toffset = 0, tcursor = 0, flags = 0;
     size_t queue = 0, sq_queue = 0, sq_desc = 0, sq_tuples = 0;      // object batches only
+    // per-band lists of the draw-order fill (textured batches, screens of up to MAX_BANDS bands)
+    int band_rows = 0, nbands = 0;
+    uint64_t band_capacity = 0;
+    size_t bcnt = 0, bplace = 0, blist = 0;
 };
 
 // The work arrays themselves: a context's work set, or pieces of the static scratch array.
@@ -282,6 +291,7 @@ struct WorkArrays {
     int *flags = nullptr;              // order flag (first 256 bytes), then the set-up sub-queue counters
     uint2 *queue = nullptr, *sq_queue = nullptr;
     int *sq_desc = nullptr, *sq_tuples = nullptr;
+    unsigned *bcnt = nullptr, *bplace = nullptr, *blist = nullptr;   // band lists (null: the draw-order fill reads every header)
 };
 
 BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edges, uint64_t min_capacity, bool screen_prp = false)
@@ -305,6 +315,17 @@ BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edge
     p.toffset = (size_t)(c->ntiles + 1) * sizeof(unsigned);
     p.tcursor = (size_t)c->ntiles * sizeof(unsigned);
     p.flags = kScratchBytes;
+    int R, nb;
+    const bool want_lists = c->order_lists == LT_ORDER_LISTS_ALWAYS || (c->order_lists == 0 && np >= BAND_LIST_MIN_POLYS);
+    if (dim == 8 && c->order_mode != LT_ORDER_NEVER && want_lists && band_lists_possible(c->W, c->H, &R, &nb)) {
+        p.band_rows = R; p.nbands = nb;
+        // a polygon of h rows is in h / R + 1 bands at most; eight a polygon, and room for tall ones
+        p.band_capacity = c->list_capacity_user ? c->list_capacity_user : (uint64_t)np * 8u + (4u << 20);
+        if (p.band_capacity > 0xffffffffull) p.band_capacity = 0xffffffffull;
+        p.bcnt = (size_t)((np + 1023) / 1024) * nb * sizeof(unsigned);
+        p.bplace = (size_t)2 * nb * sizeof(unsigned);
+        p.blist = (size_t)p.band_capacity * sizeof(unsigned);
+    }
     if (!screen) {
         p.queue = (size_t)p.qcap * QUEUES * sizeof(uint2);
         p.sq_queue = p.queue;
@@ -416,7 +437,17 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
     if (ordered_follows) {
         if ((rc = stage_begin(c, 4, rs))) return rc;
         launch_raster(rs, na, tile_w, ra, nullptr, nullptr);
-        HIPCHK(c, launch_ordered(rs, ra, c->device));
+        BandArgs ba{};
+        if (wa.blist) {
+            ba.hdr = wa.hdr; ba.np = np;
+            ba.R = pl.band_rows; ba.nb = pl.nbands;
+            ba.cnt = wa.bcnt; ba.base = wa.bplace; ba.total = wa.bplace + pl.nbands;
+            ba.list = wa.blist; ba.capacity = pl.band_capacity;
+            ba.alloc = (unsigned *)(order_flag + 1);
+            ba.order_flag = order_flag; ba.order_gen = order_gen; ba.force_order = ra.force_order;
+            ba.status = c->status;
+        }
+        HIPCHK(c, launch_ordered(rs, ra, c->device, wa.blist ? &ba : nullptr));
         if ((rc = stage_end(c, 4, rs))) return rc;
         if (raster_done) HIPCHK(c, hipEventRecord(raster_done, rs));
     } else if (timed(c, 4)) {
@@ -482,12 +513,18 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     if (!screen && (rc = ensure(c, w.sq_queue, pl.sq_queue))) return rc;
     if (!screen && (rc = ensure(c, w.sq_desc, pl.sq_desc))) return rc;
     if (!screen && (rc = ensure(c, w.sq_tuples, pl.sq_tuples))) return rc;
+    if (pl.nbands) {
+        if ((rc = ensure(c, w.bcnt, pl.bcnt))) return rc;
+        if ((rc = ensure(c, w.bplace, pl.bplace))) return rc;
+        if ((rc = ensure(c, w.blist, pl.blist))) return rc;
+    }
     WorkArrays wa;
     wa.hdr = (PrimHdr *)w.hdr.p; wa.edges = (int *)w.edges.p; wa.prp = (int *)w.prp.p;
     wa.list = (unsigned *)w.list.p; wa.tcount = (unsigned *)w.tcount.p; wa.toffset = (unsigned *)w.toffset.p;
     wa.tcursor = (unsigned *)w.tcursor.p; wa.flags = (int *)w.scratch.p;
     wa.queue = (uint2 *)w.queue.p; wa.sq_queue = (uint2 *)w.sq_queue.p;
     wa.sq_desc = (int *)w.sq_desc.p; wa.sq_tuples = (int *)w.sq_tuples.p;
+    if (pl.nbands) { wa.bcnt = (unsigned *)w.bcnt.p; wa.bplace = (unsigned *)w.bplace.p; wa.blist = (unsigned *)w.blist.p; }
     rc = issue_batch(c, wa, pl, gs, rs, c->pipelined ? w.geom_done : nullptr, c->pipelined ? w.raster_done : nullptr, true,
                      screen, dim, m, d_verts, nv, d_polys, d_aux, np, d_pv, npv, render_type, log_focus, force_linear, d_prp_src);
     if (rc) return rc;
@@ -645,7 +682,7 @@ int lt_ctx_destroy(lt_ctx *c)
         if (b->p) (void)hipFree(b->p);
     for (lt_ctx::Work &w : c->work) {
         DevBuf *wb[] = {&w.hdr, &w.edges, &w.prp, &w.list, &w.tcount, &w.toffset, &w.tcursor, &w.queue, &w.scratch,
-                        &w.sq_desc, &w.sq_tuples, &w.sq_queue};
+                        &w.sq_desc, &w.sq_tuples, &w.sq_queue, &w.bcnt, &w.bplace, &w.blist};
         for (DevBuf *b : wb)
             if (b->p) (void)hipFree(b->p);
         if (w.geom_done) (void)hipEventDestroy(w.geom_done);
@@ -706,8 +743,12 @@ int lt_set_tile_width(lt_ctx *c, int width)
 
 int lt_set_textured_order(lt_ctx *c, int mode)
 {
-    if (!c || mode < LT_ORDER_AUTO || mode > LT_ORDER_NEVER) return fail(c, LT_ERR_ARG, "lt_set_textured_order: mode %d", mode);
+    const int lists = mode & (LT_ORDER_LISTS_ALWAYS | LT_ORDER_LISTS_NEVER);
+    mode &= ~(LT_ORDER_LISTS_ALWAYS | LT_ORDER_LISTS_NEVER);
+    if (!c || mode < LT_ORDER_AUTO || mode > LT_ORDER_NEVER || lists == (LT_ORDER_LISTS_ALWAYS | LT_ORDER_LISTS_NEVER))
+        return fail(c, LT_ERR_ARG, "lt_set_textured_order: mode %d", mode | lists);
     c->order_mode = mode;
+    c->order_lists = lists;
     return LT_OK;
 }
 

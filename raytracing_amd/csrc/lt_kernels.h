@@ -121,6 +121,24 @@ struct RasterArgs {
     Status *status;
 };
 
+// Per-band polygon lists of the draw-order fill (textured batches whose light varies along
+// spans): band b holds rows [b*R, b*R + R); its list is list[base[b] .. base[b] + total[b]).
+constexpr int MAX_BANDS = 1024;            // LDS bit matrix of the band binning: MAX_BANDS x 33 words
+struct BandArgs {
+    const PrimHdr *hdr;
+    int np;
+    int R, nb;                     // rows per band, number of bands
+    unsigned *cnt;                 // [chunks of 1024 slots][nb]: entries of the chunk, then their exclusive prefix along the chunks
+    unsigned *base, *total;        // [nb]
+    unsigned *list;
+    unsigned long long capacity;   // entries
+    unsigned *alloc;               // end of the lists handed out so far; zero before the batch, zeroed again by the fill
+    const int *order_flag;
+    int order_gen, force_order;
+    Status *status;
+};
+bool band_lists_possible(int W, int H, int *R, int *nb);
+
 // Shading pre-pass (M_shade_polygon_object, EngPoly.cpp:464-493).
 constexpr int MAX_LIGHTS = 16;
 struct ShadeArgs {
@@ -152,7 +170,7 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tile
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
                     unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done);
 void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop);
-hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device);   // textured batches only; `device` is current
+hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands);   // textured batches only; `device` is current
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 
 }  // namespace lt

@@ -1489,22 +1489,15 @@ __device__ __forceinline__ bool depth_row_mem(const int *__restrict__ edges, int
     return true;
 }
 
-// Colour of the pixel (gx, gy) of a polygon row [beg, end] with start values S and
-// per-pixel increments I (GraphicsPoly.cpp:372 shaded, :465-491 linear texture,
-// :592-675 perspective texture).  `kl` is the number of increments the light
-// accumulators have taken when this pixel is drawn: gx - beg for the shaded fill, the
-// number of earlier pixels of the span that passed the depth test for the textured
-// fills (GraphicsPoly.cpp:485-493, 666-674).
+// Address of the texel that the textured fills read at pixel (gx, gy) of a polygon row
+// [beg, end] with start values S and per-pixel increments I (GraphicsPoly.cpp:465-486 linear
+// texture, :592-667 perspective texture); null for the fills that use the polygon's colour.
 template <int NA>
-__device__ __forceinline__ int pixel_colour(const RasterArgs &a, const int4 h, int poly, int gx, int gy, int beg,
-                                            int end, const int (&S)[NA], const int (&I)[NA], int kl)
+__device__ __forceinline__ const int *texel_address(const RasterArgs &a, const int4 h, int poly, int gx, int gy, int beg,
+                                                    int end, const int (&S)[NA], const int (&I)[NA])
 {
     const int kind = (h.w >> 8) & 0xff, ptex = (h.w >> 16) & 0xff;
     const int kx = gx - beg;
-    const int lr = wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16;
-    const int lg = wadd(S[2 % NA], wmul(kl, I[2 % NA])) >> 16;
-    const int lb = wadd(S[3 % NA], wmul(kl, I[3 % NA])) >> 16;
-    int base = h.z;
     if (NA == 6 && kind == KIND_TEX_PRP) {
         // exact texture coordinates at the ends of 32-pixel runs, linear in between
         const int4 c0 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[0];
@@ -1541,7 +1534,7 @@ __device__ __forceinline__ int pixel_colour(const RasterArgs &a, const int4 h, i
         const int lg2 = a.tex_log[ptex];
         const int mask = wsub(wshl(1, lg2 + 16), 1);
         const int tu = wadd(t0u, wmul(q, iu)) & mask, tv = wadd(t0v, wmul(q, iv)) & mask;
-        base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
+        return a.tex_ptr[ptex] + (((tv >> 16) << lg2) + (tu >> 16));
     }
     if (NA == 6 && kind == KIND_TEX_LIN) {
         // GraphicsPoly.cpp:443-446,465,486: wrap, then fetch the texel
@@ -1549,9 +1542,26 @@ __device__ __forceinline__ int pixel_colour(const RasterArgs &a, const int4 h, i
         const int mask = wsub(wshl(1, lg2 + 16), 1);
         const int tu = wadd(S[4 % NA], wmul(kx, I[4 % NA])) & mask;
         const int tv = wadd(S[5 % NA], wmul(kx, I[5 % NA])) & mask;
-        base = a.tex_ptr[ptex][((tv >> 16) << lg2) + (tu >> 16)];
+        return a.tex_ptr[ptex] + (((tv >> 16) << lg2) + (tu >> 16));
     }
-    return cl_light(base, lr, lg, lb);
+    return nullptr;
+}
+
+// Colour of the pixel (gx, gy) of a polygon row [beg, end] with start values S and
+// per-pixel increments I (GraphicsPoly.cpp:372 shaded, :465-491 linear texture,
+// :592-675 perspective texture).  `kl` is the number of increments the light
+// accumulators have taken when this pixel is drawn: gx - beg for the shaded fill, the
+// number of earlier pixels of the span that passed the depth test for the textured
+// fills (GraphicsPoly.cpp:485-493, 666-674).
+template <int NA>
+__device__ __forceinline__ int pixel_colour(const RasterArgs &a, const int4 h, int poly, int gx, int gy, int beg,
+                                            int end, const int (&S)[NA], const int (&I)[NA], int kl)
+{
+    const int lr = wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16;
+    const int lg = wadd(S[2 % NA], wmul(kl, I[2 % NA])) >> 16;
+    const int lb = wadd(S[3 % NA], wmul(kl, I[3 % NA])) >> 16;
+    const int *t = texel_address<NA>(a, h, poly, gx, gy, beg, end, S, I);
+    return cl_light(t ? *t : h.z, lr, lg, lb);
 }
 
 // Draw-order fill for textured batches whose light varies along spans.  There the
@@ -1636,6 +1646,299 @@ __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
         a.zbuf[g] = zt[p];
         a.cbuf[g] = ct[p];
     }
+    if (lane == 0 && frags) atomicAdd(&(a.status + (blockIdx.x % STATUS_SLOTS))->fragments, frags);
+}
+
+// ---- draw-order fill from per-band polygon lists
+//
+// The kernel above reads every header in every band.  For batches of millions of polygons the
+// bands get lists instead: for every band of R rows, the slots of the polygons that have rows
+// in it, in slot (= draw) order.  They come from a stable counting sort over (slot, band)
+// pairs.  A workgroup takes a chunk of BAND_CHUNK consecutive slots and sets, in an LDS bit
+// matrix [band][slot in chunk], the bit of every (polygon, band) pair; a row of that matrix
+// read from bit 0 upwards is the chunk's part of the band's list, already in order.
+//   band_bin_kernel<false>   bit matrix -> cnt[chunk][band] = bits set in the row
+//   band_scan_kernel         cnt -> exclusive prefix along the chunks; every band gets its
+//                            list's place (base, total) from one running allocation
+//   band_bin_kernel<true>    bit matrix again -> list[base[band] + cnt[chunk][band] + rank]
+// All of them return at once unless the batch is to be filled in draw order.
+
+constexpr int BAND_CHUNK = 1024;
+constexpr int BAND_WORDS = BAND_CHUNK / 32;
+constexpr int BAND_PITCH = BAND_WORDS + 1;       // LDS words between two bands' rows (bank spread)
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) band_bin_kernel(BandArgs a)
+{
+    extern __shared__ unsigned band_bits[];
+    if (!(a.force_order || *a.order_flag == a.order_gen)) return;
+    const int t = threadIdx.x;
+    for (int i = t; i < a.nb * BAND_PITCH; i += 256) band_bits[i] = 0u;
+    __syncthreads();
+    const int chunk = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < BAND_CHUNK / 256; k++) {
+        const int idx = k * 256 + t, slot = chunk * BAND_CHUNK + idx;
+        if (slot < a.np) {
+            const int4 h = ((const int4 *)a.hdr)[slot];
+            if ((h.w & 0xff) != 0) {
+                const int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff;
+                const int b0 = miny / a.R, b1 = min((maxy - 1) / a.R, a.nb - 1);
+                for (int b = b0; b <= b1; b++) atomicOr(&band_bits[b * BAND_PITCH + (idx >> 5)], 1u << (idx & 31));
+            }
+        }
+    }
+    __syncthreads();
+    for (int b = t; b < a.nb; b += 256) {
+        const unsigned *row = band_bits + b * BAND_PITCH;
+        if (!SCATTER) {
+            unsigned c = 0;
+#pragma unroll 8
+            for (int k = 0; k < BAND_WORDS; k++) c += __popc(row[k]);
+            a.cnt[(size_t)chunk * a.nb + b] = c;
+        } else {
+            unsigned long long pos = (unsigned long long)a.base[b] + a.cnt[(size_t)chunk * a.nb + b];
+            for (int k = 0; k < BAND_WORDS; k++) {
+                unsigned w = row[k];
+                while (w) {
+                    const int bit = __ffs((int)w) - 1;
+                    w &= w - 1;
+                    if (pos < a.capacity) a.list[pos] = (unsigned)(chunk * BAND_CHUNK + k * 32 + bit);
+                    pos++;
+                }
+            }
+        }
+    }
+}
+
+// One workgroup per 64 bands (a lane per band), its 16 waves each a stretch of the chunks.
+__global__ void __launch_bounds__(1024) band_scan_kernel(BandArgs a, int nchunks)
+{
+    __shared__ unsigned seg[16][64];
+    if (!(a.force_order || *a.order_flag == a.order_gen)) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int b = blockIdx.x * 64 + lane;
+    const bool on = b < a.nb;
+    const int per = (nchunks + 15) / 16, c0 = w * per, c1 = min(c0 + per, nchunks);
+    unsigned s = 0;
+    if (on)
+        for (int c = c0; c < c1; c++) s += a.cnt[(size_t)c * a.nb + b];
+    seg[w][lane] = s;
+    __syncthreads();
+    unsigned pre = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const unsigned v = seg[k][lane];
+        pre += k < w ? v : 0u;
+        tot += v;
+    }
+    if (w == 0) {
+        unsigned incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const unsigned all = __shfl(incl, 63);
+        unsigned g = 0;
+        if (lane == 0 && all) {
+            g = atomicAdd(a.alloc, all);
+            const unsigned long long end = (unsigned long long)g + all;
+            if (end > a.capacity)
+                atomicAdd(&a.status->list_overflow, end - (a.capacity > g ? a.capacity : (unsigned long long)g));
+        }
+        g = __shfl(g, 0);
+        if (on) { a.base[b] = g + incl - tot; a.total[b] = tot; }
+    }
+    __syncthreads();
+    if (on) {
+        unsigned run = pre;
+        for (int c = c0; c < c1; c++) {
+            const size_t i = (size_t)c * a.nb + b;
+            const unsigned v = a.cnt[i];
+            a.cnt[i] = run;
+            run += v;
+        }
+    }
+}
+
+// The draw-order fill of one band from its list.  Every wave walks the whole list, 64
+// polygons at a time, for each of its rows (every fourth row of the band):
+//  - all 64 lanes evaluate their polygon's row (ends, start values, increments): that part
+//    does not depend on the draw order;
+//  - spans of up to 16 pixels -- the case of batches of many small polygons -- are then drawn
+//    one per lane, pixel by pixel, in rounds: a lane may draw once no earlier polygon of the 64
+//    that is still waiting has a span near its own.  Lanes claim the 8- or 16-pixel cells of
+//    the row that their span touches with their lane number (an LDS minimum); a lane that
+//    holds all of its cells has no earlier neighbour left and draws, then frees its cells.
+//    The lowest waiting lane always holds its cells, so every round draws at least one span;
+//  - a group of 64 with a longer span in it is drawn polygon after polygon, 64 pixels of a
+//    span per step (ballot and prefix count of the depth-test passes), as in the kernel above.
+template <int NA>
+__global__ void __launch_bounds__(256) ordered_list_kernel(RasterArgs a, BandArgs ba, int cshift)
+{
+    constexpr int ESZ = edge_ints(NA);
+    extern __shared__ int band_lds[];
+    if (!(a.force_order || *a.order_flag == a.order_gen)) return;
+    const int W = a.W, R = ba.R;
+    const int ncell = (W >> cshift) + 1;
+    int *zt = band_lds, *ct = band_lds + R * W;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    unsigned *cells = (unsigned *)(band_lds + 2 * R * W) + wv * ncell;
+    const int band = blockIdx.x;
+    if (band == 0 && t == 0) *ba.alloc = 0u;          // every list has its place by now: ready for the next batch
+    const int y0 = max(band * R, a.band_y0), y1 = min(min(band * R + R, a.H), a.band_y1);
+    if (y0 >= y1) return;
+    const int npx = (y1 - y0) * W;
+    for (int p = t; p < npx; p += 256) {
+        const size_t g = (size_t)y0 * W + p;
+        zt[p] = a.clear_pending ? INT_MAX : a.zbuf[g];
+        ct[p] = a.clear_pending ? a.clear_colour : a.cbuf[g];
+    }
+    for (int p = lane; p < ncell; p += 64) cells[p] = ~0u;
+    __syncthreads();
+
+    const unsigned long long lb = ba.base[band];
+    unsigned ln = ba.total[band];
+    if (lb + ln > ba.capacity) ln = ba.capacity > lb ? (unsigned)(ba.capacity - lb) : 0u;     // overflow is reported by the scan
+    unsigned long long frags = 0;
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    for (unsigned e0 = 0; e0 < ln; e0 += 64) {
+        const unsigned ei = e0 + (unsigned)lane;
+        int poly = ei < ln ? (int)ba.list[lb + ei] : -1;
+        if ((unsigned)poly >= (unsigned)a.np) poly = -1;
+        int4 h = zero4;
+        int2 xy[3] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
+        if (poly >= 0) {
+            h = *record_header(a.edges, ESZ / 4, poly);
+#pragma unroll
+            for (int e = 0; e < 3; e++) xy[e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
+        }
+        const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff;
+        const int pr0 = h.x & 0xffff, pr1 = (h.x >> 16) & 0xffff;
+        for (int y = y0 + wv; y < y1; y += 4) {
+            int S[NA], E[NA], I[NA], beg = 0, end = -1;
+            bool hit = poly >= 0 && ne != 0 && y >= pr0 && y < pr1;
+            if (hit) hit = row_ends<NA>(a.edges, a.np, poly, ne, y, beg, end, S, E, xy);
+#pragma unroll
+            for (int q = 0; q < NA; q++) I[q] = 0;
+            if (hit) {
+                int span = end - beg;
+                if (span == 0) span = 1;
+                const double rs = drcp(span);
+#pragma unroll
+                for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+                frags += (unsigned long long)(end - beg + 1);
+            }
+            const unsigned long long hits = __ballot(hit);
+            if (!hits) continue;
+            int *zrow = zt + (y - y0) * W, *crow = ct + (y - y0) * W;
+            if (__ballot(hit && end - beg >= 16) == 0ull) {
+                // ---- short spans, one per lane
+                const int c0 = beg >> cshift, c1 = end >> cshift;          // at most three cells
+                unsigned long long rem = hits;
+                while (rem) {
+                    const bool mine = (rem >> lane) & 1ull;
+                    if (mine) {
+                        atomicMin(&cells[c0], (unsigned)lane);
+                        if (c1 > c0) atomicMin(&cells[c0 + 1], (unsigned)lane);
+                        if (c1 > c0 + 1) atomicMin(&cells[c1], (unsigned)lane);
+                    }
+                    LDS_WAVE_SYNC();
+                    bool go = false;
+                    if (mine)
+                        go = cells[c0] == (unsigned)lane && (c1 <= c0 || cells[c0 + 1] == (unsigned)lane) &&
+                             (c1 <= c0 + 1 || cells[c1] == (unsigned)lane);
+                    LDS_WAVE_SYNC();
+                    if (go) {
+                        // depth tests first (GraphicsPoly.cpp:469-472), then the colours of the passes
+                        unsigned pass = 0u;
+                        int z = S[0];
+                        const int n = end - beg;
+                        for (int k = 0; k <= n; k++) {
+                            const int zi = z >> 16;
+                            if (zrow[beg + k] > zi) { zrow[beg + k] = zi; pass |= 1u << k; }
+                            z = wadd(z, I[0]);
+                        }
+                        int nb = 0;
+                        while (pass) {
+                            // up to four passes at a time: their texel loads are in flight together
+                            int kk[4];
+                            const int *tp[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                kk[q] = pass ? __ffs((int)pass) - 1 : -1;
+                                pass &= pass - 1u;            // 0 stays 0
+                                tp[q] = nullptr;
+                                if (kk[q] >= 0 && kind != KIND_FLAT) tp[q] = texel_address<NA>(a, h, poly, beg + kk[q], y, beg, end, S, I);
+                            }
+                            int src[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) src[q] = tp[q] ? *tp[q] : h.z;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                if (kk[q] < 0) continue;
+                                int c = h.z;
+                                if (NA > 1 && kind != KIND_FLAT) {
+                                    const int kl = kind >= KIND_TEX_LIN ? nb : kk[q];
+                                    c = cl_light(src[q], wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16,
+                                                 wadd(S[2 % NA], wmul(kl, I[2 % NA])) >> 16,
+                                                 wadd(S[3 % NA], wmul(kl, I[3 % NA])) >> 16);
+                                }
+                                crow[beg + kk[q]] = c;
+                                nb++;
+                            }
+                        }
+                        cells[c0] = ~0u;
+                        if (c1 > c0) cells[c0 + 1] = ~0u;
+                        if (c1 > c0 + 1) cells[c1] = ~0u;
+                    }
+                    LDS_WAVE_SYNC();
+                    rem &= ~__ballot(go);
+                }
+            } else {
+                // ---- one polygon after the other, 64 pixels of its span per step
+                unsigned long long m = hits;
+                while (m) {
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int4 bh = make_int4(__shfl(h.x, src), __shfl(h.y, src), __shfl(h.z, src), __shfl(h.w, src));
+                    const int bpoly = __shfl(poly, src), bbeg = __shfl(beg, src), bend = __shfl(end, src);
+                    const int bkind = (bh.w >> 8) & 0xff;
+                    int bS[NA], bI[NA];
+#pragma unroll
+                    for (int q = 0; q < NA; q++) { bS[q] = __shfl(S[q], src); bI[q] = __shfl(I[q], src); }
+                    int carry = 0;
+                    for (int xb = bbeg; xb <= bend; xb += 64) {
+                        const int x = xb + lane;
+                        const bool in = x <= bend;
+                        const int k = x - bbeg;
+                        const int zi = wadd(bS[0], wmul(k, bI[0])) >> 16;
+                        const bool pass = in && zrow[x < W ? x : W - 1] > zi;
+                        const unsigned long long pm = __ballot(pass);
+                        if (pass) {
+                            const int nb = carry + __popcll(pm & ((1ull << lane) - 1ull));
+                            int c = bh.z;
+                            if (NA > 1 && bkind != KIND_FLAT)
+                                c = pixel_colour<NA>(a, bh, bpoly, x, y, bbeg, bend, bS, bI, bkind >= KIND_TEX_LIN ? nb : k);
+                            zrow[x] = zi;
+                            crow[x] = c;
+                        }
+                        carry += __popcll(pm);
+                    }
+                    LDS_WAVE_SYNC();
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int p = t; p < npx; p += 256) {
+        const size_t g = (size_t)y0 * W + p;
+        a.zbuf[g] = zt[p];
+        a.cbuf[g] = ct[p];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) frags += __shfl_down(frags, d);
     if (lane == 0 && frags) atomicAdd(&(a.status + (blockIdx.x % STATUS_SLOTS))->fragments, frags);
 }
 
@@ -2067,19 +2370,67 @@ int ordered_band_rows(int W, int H)
     return r;
 }
 
-hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device)
+// Rows per band, cell size and LDS bytes of the list-driven draw-order kernel: the band's
+// depth and colour rows plus one row of cells per wave.
+void ordered_list_layout(int W, int H, int *R, int *cshift, size_t *lds)
 {
-    const int R = ordered_band_rows(a.W, a.H);
-    const size_t lds = (size_t)R * a.W * 8;
-    // the attribute belongs to the function on one device: once per device (which is current)
-    static std::atomic<bool> attr_set[MAX_DEVICES];
+    *cshift = W > 8192 ? 4 : 3;
+    const size_t cells = 4 * (size_t)((W >> *cshift) + 1) * sizeof(unsigned);
+    int r = (int)((150 * 1024 - cells) / (8 * (size_t)W));
+    if (r < 1) r = 1;
+    if (r > 16) r = 16;
+    if (r > H) r = H;
+    *R = r;
+    *lds = (size_t)r * W * 8 + cells;
+}
+
+bool band_lists_possible(int W, int H, int *R, int *nb)
+{
+    int cs;
+    size_t lds;
+    ordered_list_layout(W, H, R, &cs, &lds);
+    *nb = (H + *R - 1) / *R;
+    return *nb <= MAX_BANDS;
+}
+
+// the dynamic-LDS attribute belongs to the function on one device: once per device (which is current)
+template <typename F>
+static hipError_t allow_large_lds(F fn, std::atomic<bool> (&done)[MAX_DEVICES], int device)
+{
     if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
-    if (!attr_set[device].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute((const void *)ordered_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (!done[device].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        attr_set[device].store(true, std::memory_order_release);
+        done[device].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((ordered_kernel<6>), dim3((a.H + R - 1) / R), dim3(256), lds, s, a, R);
+    return hipSuccess;
+}
+
+// `bands` (may be null): work arrays for per-band lists; without them every band reads every header
+hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands)
+{
+    static std::atomic<bool> set_walk[MAX_DEVICES], set_list[MAX_DEVICES], set_count[MAX_DEVICES], set_scatter[MAX_DEVICES];
+    hipError_t e;
+    if (!bands) {
+        const int R = ordered_band_rows(a.W, a.H);
+        const size_t lds = (size_t)R * a.W * 8;
+        if ((e = allow_large_lds(ordered_kernel<6>, set_walk, device)) != hipSuccess) return e;
+        hipLaunchKernelGGL((ordered_kernel<6>), dim3((a.H + R - 1) / R), dim3(256), lds, s, a, R);
+        return hipSuccess;
+    }
+    int R, cshift;
+    size_t lds;
+    ordered_list_layout(a.W, a.H, &R, &cshift, &lds);
+    if (R != bands->R) return hipErrorInvalidValue;
+    if ((e = allow_large_lds(ordered_list_kernel<6>, set_list, device)) != hipSuccess) return e;
+    if ((e = allow_large_lds(band_bin_kernel<false>, set_count, device)) != hipSuccess) return e;
+    if ((e = allow_large_lds(band_bin_kernel<true>, set_scatter, device)) != hipSuccess) return e;
+    const int nchunks = (a.np + BAND_CHUNK - 1) / BAND_CHUNK;
+    const size_t bits = (size_t)bands->nb * BAND_PITCH * sizeof(unsigned);
+    hipLaunchKernelGGL((band_bin_kernel<false>), dim3(nchunks), dim3(256), bits, s, *bands);
+    hipLaunchKernelGGL(band_scan_kernel, dim3((bands->nb + 63) / 64), dim3(1024), 0, s, *bands, nchunks);
+    hipLaunchKernelGGL((band_bin_kernel<true>), dim3(nchunks), dim3(256), bits, s, *bands);
+    hipLaunchKernelGGL((ordered_list_kernel<6>), dim3(bands->nb), dim3(256), lds, s, a, *bands, cshift);
     return hipSuccess;
 }
 

@@ -1,0 +1,129 @@
+"""The draw-order fill (textured polygons whose light varies along spans: the reference
+advances light only on depth-test passes, GraphicsPoly.cpp:485-493, 666-674) with per-band
+polygon lists, against the CPU restatement and against the variant that reads every header:
+small polygons (one span per lane, drawn in rounds), large and clipped polygons (span sweeps),
+both texture mappers, several batches in one frame, row bands, list overflow."""
+import numpy as np
+import pytest
+
+from raytracing_amd import bands as B, scenes as S
+
+pytestmark = pytest.mark.gpu
+LISTS_ALWAYS, LISTS_NEVER = 4, 8
+
+
+@pytest.fixture(scope="module")
+def env():
+    import oracle.port as P
+    from raytracing_amd import gpu as G
+    return P, G
+
+
+def _oracle(P, scenes, w, h, clear=(0x102030, 255, 255, 255)):
+    orc = P.Oracle(w, h)
+    orc.clear(*clear)
+    orc.reset_counters()
+    for sc in scenes:
+        for hnd, (tex, lg) in enumerate(sc.textures):
+            orc.set_texture(hnd, tex, lg)
+        orc.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type, sc.log_focus, sc.force_linear)
+    return orc
+
+
+def _gpu(P, G, scenes, w, h, mode, clear=(0x102030, 255, 255, 255), band=None, capacity=0):
+    ctx = G.Context(w, h)
+    ctx.set_textured_order(mode)
+    if capacity:
+        ctx.set_list_capacity(capacity)
+    if band:
+        ctx.set_band(*band)
+    ctx.clear(P.cl_light(*clear))
+    ctx.reset_counters()
+    for sc in scenes:
+        ctx.submit_scene(sc)
+    return ctx
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_polygons_of_all_sizes(env, seed):
+    """3..6-gon fuzz: near-plane and border clipping, spans from one pixel to the whole row"""
+    P, G = env
+    sc = S.gen_fuzz_polys(150, 320, 200, 8, 7700 + seed, render_type=S.M_TEXTURED, textured=True, equal_lights=False, zrange=(12, 2000))
+    orc = _oracle(P, [sc], 320, 200)
+    ctx = _gpu(P, G, [sc], 320, 200, LISTS_ALWAYS)
+    c, z = ctx.readback(check=False)
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert ctx.counters()["fragments"] == orc.counters()["fragments"]
+
+
+@pytest.mark.parametrize("lin_percent", [100, 70])
+def test_small_triangles_1080p_lists_and_headers_agree(env, lin_percent):
+    """60k small textured triangles with random vertex lights at 1080p, some through the
+    perspective mapper: the restatement, the list-driven fill and the every-header fill"""
+    P, G = env
+    sc = S.gen_c3(60000, 1920, 1080, 10, radius=10, equal_lights=False, lin_percent=lin_percent, seed=0xC0FFEE53, regular_mapping=True)
+    orc = _oracle(P, [sc], 1920, 1080)
+    frames = []
+    for mode in (LISTS_ALWAYS, LISTS_NEVER, 0):
+        ctx = _gpu(P, G, [sc], 1920, 1080, mode)
+        c, z = ctx.readback(check=False)
+        frames.append((c, z, ctx.counters()["fragments"]))
+        ctx.close()
+    for c, z, fr in frames:
+        assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+        assert fr == orc.counters()["fragments"]
+
+
+def test_dense_overlap_many_rounds(env):
+    """thousands of tiny triangles piled on a few cells: long chains of spans that must wait
+    for each other inside one group of 64"""
+    P, G = env
+    sc = S.gen_c3(30000, 256, 96, 7, radius=5, equal_lights=False, lin_percent=100, seed=0xC0FFEE54)
+    orc = _oracle(P, [sc], 256, 96)
+    ctx = _gpu(P, G, [sc], 256, 96, LISTS_ALWAYS)
+    c, z = ctx.readback(check=False)
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+
+
+def test_several_batches_in_one_frame_and_frames_in_flight(env):
+    """three textured batches drawn over each other, twice without a flush (two frames in
+    flight, work sets in turns): every batch has its own lists"""
+    P, G = env
+    scs = [S.gen_c3(25000, 640, 480, 9, radius=12, equal_lights=False, lin_percent=100, seed=0xC0FFEE60 + k) for k in range(3)]
+    for sc in scs[1:]:
+        sc.textures = scs[0].textures
+    orc = _oracle(P, scs, 640, 480)
+    ctx = _gpu(P, G, scs, 640, 480, LISTS_ALWAYS)
+    ctx.clear(P.cl_light(0x102030, 255, 255, 255))
+    for sc in scs:
+        ctx.submit_scene(sc)
+    c, z = ctx.readback(check=False)
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert ctx.counters()["fragments"] == 2 * orc.counters()["fragments"]
+
+
+def test_row_bands(env):
+    """a context that draws only its band of rows (sort-first split) with lists"""
+    P, G = env
+    sc = S.gen_c3(40000, 800, 600, 9, radius=14, equal_lights=False, lin_percent=100, seed=0xC0FFEE70)
+    orc = _oracle(P, [sc], 800, 600)
+    c = np.empty((600, 800), np.int32)
+    z = np.empty((600, 800), np.int32)
+    frags = 0
+    for y0, y1 in B.all_bands(3, 600):
+        ctx = _gpu(P, G, [sc], 800, 600, LISTS_ALWAYS, band=(y0, y1))
+        cb, zb = ctx.readback(check=False)
+        c[y0:y1], z[y0:y1] = cb[y0:y1], zb[y0:y1]
+        frags += ctx.counters()["fragments"]
+        ctx.close()
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert frags == orc.counters()["fragments"]
+
+
+def test_list_overflow_is_reported(env):
+    P, G = env
+    sc = S.gen_c3(30000, 640, 480, 9, radius=12, equal_lights=False, lin_percent=100, seed=0xC0FFEE80)
+    ctx = _gpu(P, G, [sc], 640, 480, LISTS_ALWAYS, capacity=4000)
+    with pytest.raises(G.LtError) as e:
+        ctx.flush()
+    assert e.value.code == -4
