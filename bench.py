@@ -682,7 +682,7 @@ def main():
         if headline and not args.no_side_lines:
             ctx.close()
             del d_verts, d_polys, d_pv
-            print_line["c3_4k"] = c3_side(torch, dist, dev, local_rank, 10_000_000, 1_000_000)
+            print_line["c3_4k"] = c3_side(torch, dist, dev, local_rank, 10_000_000, 10_000_000)
     if rank == 0:
         assert print_line["n_gpus"] == args.gpus
         print(json.dumps(print_line), flush=True)

@@ -1489,6 +1489,39 @@ __device__ __forceinline__ bool depth_row_mem(const int *__restrict__ edges, int
     return true;
 }
 
+// One linear run of the perspective mapper (GraphicsPoly.cpp:614-640): exact texture coordinates
+// at the run's two ends xs, xe (pixels from the screen centre) on screen row gy, and the
+// per-pixel increments over `rspan` pixels (0: the run is a single pixel).
+__device__ __forceinline__ void prp_run(const RasterArgs &a, int poly, int gy, int xs, int xe, int rspan, int &t0u, int &t0v,
+                                        int &iu, int &iv)
+{
+    const int4 c0 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[0];
+    const int4 c1 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[1];
+    const int4 c2 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[2];
+    const int lf = a.log_focus, lsc = c2.w;
+    const int yp = gy - a.H / 2;
+    const int xx = wadd(wmul(yp, c0.y) >> lf, c0.z), yy = wadd(wmul(yp, c1.x) >> lf, c1.y);
+    const int zz = wadd(wmul(yp, c1.w) >> lf, c2.x);
+    int t1u = 0, t1v = 0;
+    t0u = 0; t0v = 0;
+    {
+        const int zzz = wadd(zz, wmul(xs, c1.z) >> lf);
+        if (zzz != 0) {
+            t0u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xs, c0.x) >> lf), lsc), zzz), 16), c2.y);
+            t0v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xs, c0.w) >> lf), lsc), zzz), 16), c2.z);
+        }
+    }
+    {
+        const int zzz = wadd(zz, wmul(xe, c1.z) >> lf);
+        if (zzz != 0) {
+            t1u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xe, c0.x) >> lf), lsc), zzz), 16), c2.y);
+            t1v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xe, c0.w) >> lf), lsc), zzz), 16), c2.z);
+        }
+    }
+    iu = 0; iv = 0;
+    if (rspan != 0) { const double rr = drcp(rspan); iu = tdivr(wsub(t1u, t0u), rr); iv = tdivr(wsub(t1v, t0v), rr); }
+}
+
 // Address of the texel that the textured fills read at pixel (gx, gy) of a polygon row
 // [beg, end] with start values S and per-pixel increments I (GraphicsPoly.cpp:465-486 linear
 // texture, :592-667 perspective texture); null for the fills that use the polygon's colour.
@@ -1500,13 +1533,7 @@ __device__ __forceinline__ const int *texel_address(const RasterArgs &a, const i
     const int kx = gx - beg;
     if (NA == 6 && kind == KIND_TEX_PRP) {
         // exact texture coordinates at the ends of 32-pixel runs, linear in between
-        const int4 c0 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[0];
-        const int4 c1 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[1];
-        const int4 c2 = ((const int4 *)(a.prp + (size_t)poly * PRP_INTS))[2];
-        const int lf = a.log_focus, lsc = c2.w;
-        const int begp = beg - a.W / 2, endp = end - a.W / 2, xp = gx - a.W / 2, yp = gy - a.H / 2;
-        const int xx = wadd(wmul(yp, c0.y) >> lf, c0.z), yy = wadd(wmul(yp, c1.x) >> lf, c1.y);
-        const int zz = wadd(wmul(yp, c1.w) >> lf, c2.x);
+        const int begp = beg - a.W / 2, endp = end - a.W / 2, xp = gx - a.W / 2;
         const int d = xp - begp;
         int xs, q;                                   // run start boundary, pixel offset in the run
         if (d <= 32) { xs = begp; q = d; }
@@ -1514,23 +1541,8 @@ __device__ __forceinline__ const int *texel_address(const RasterArgs &a, const i
         int xe = xs + 32;
         if (xe > endp) xe = endp;
         const int rspan = d <= 32 ? xe - xs : xe - xs - 1;
-        int t0u = 0, t0v = 0, t1u = 0, t1v = 0;
-        {
-            const int zzz = wadd(zz, wmul(xs, c1.z) >> lf);
-            if (zzz != 0) {
-                t0u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xs, c0.x) >> lf), lsc), zzz), 16), c2.y);
-                t0v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xs, c0.w) >> lf), lsc), zzz), 16), c2.z);
-            }
-        }
-        {
-            const int zzz = wadd(zz, wmul(xe, c1.z) >> lf);
-            if (zzz != 0) {
-                t1u = wadd(wshl(tdiv_any(wshl(wadd(xx, wmul(xe, c0.x) >> lf), lsc), zzz), 16), c2.y);
-                t1v = wadd(wshl(tdiv_any(wshl(wadd(yy, wmul(xe, c0.w) >> lf), lsc), zzz), 16), c2.z);
-            }
-        }
-        int iu = 0, iv = 0;
-        if (rspan != 0) { const double rr = drcp(rspan); iu = tdivr(wsub(t1u, t0u), rr); iv = tdivr(wsub(t1v, t0v), rr); }
+        int t0u, t0v, iu, iv;
+        prp_run(a, poly, gy, xs, xe, rspan, t0u, t0v, iu, iv);
         const int lg2 = a.tex_log[ptex];
         const int mask = wsub(wshl(1, lg2 + 16), 1);
         const int tu = wadd(t0u, wmul(q, iu)) & mask, tv = wadd(t0v, wmul(q, iv)) & mask;
@@ -1762,146 +1774,237 @@ __global__ void __launch_bounds__(1024) band_scan_kernel(BandArgs a, int nchunks
     }
 }
 
-// The draw-order fill of one band from its list.  Every wave walks the whole list, 64
-// polygons at a time, for each of its rows (every fourth row of the band):
-//  - all 64 lanes evaluate their polygon's row (ends, start values, increments): that part
-//    does not depend on the draw order;
-//  - spans of up to 16 pixels -- the case of batches of many small polygons -- are then drawn
-//    one per lane, pixel by pixel, in rounds: a lane may draw once no earlier polygon of the 64
-//    that is still waiting has a span near its own.  Lanes claim the 8- or 16-pixel cells of
-//    the row that their span touches with their lane number (an LDS minimum); a lane that
-//    holds all of its cells has no earlier neighbour left and draws, then frees its cells.
-//    The lowest waiting lane always holds its cells, so every round draws at least one span;
-//  - a group of 64 with a longer span in it is drawn polygon after polygon, 64 pixels of a
-//    span per step (ballot and prefix count of the depth-test passes), as in the kernel above.
-template <int NA>
-__global__ void __launch_bounds__(256) ordered_list_kernel(RasterArgs a, BandArgs ba, int cshift)
+// The draw-order fill of one row from its band's list: one workgroup per row (depth and colour
+// of the row in LDS), its NW waves taking groups of 64 list entries in turn (group g goes to
+// wave g mod NW).  For a group:
+//  - all 64 lanes evaluate their polygon's span on the row (ends, start values, increments);
+//    this does not depend on what is in the row, so the waves do it side by side;
+//  - then the group waits for its turn at the row's depth values (LDS word turn[0]).  Spans
+//    of up to 16 pixels -- batches of many small polygons -- are depth-tested one per lane,
+//    pixel by pixel, in rounds: a lane may go once no earlier polygon of the 64 that is still
+//    waiting has a span near its own.  Lanes claim the 8- or 16-pixel cells that their span
+//    touches with their lane number (an LDS minimum); a lane that holds all of its cells has
+//    no earlier neighbour left, tests its pixels, keeps a bit mask of the passes and frees its
+//    cells.  The lowest waiting lane always holds its cells: every round makes progress;
+//  - with the depth values updated the next group may start on them; this one computes the
+//    colours of its passes (texel loads, light from the pass count: GraphicsPoly.cpp:485-493)
+//    and writes them when its turn at the row's colours has come (turn[1]), round by round;
+//  - a group with a longer span in it waits until every earlier group has finished and is
+//    drawn polygon after polygon, 64 pixels of a span per step (ballot and prefix count of
+//    the passes), as in the kernel above.
+__device__ __forceinline__ void wait_turn(const unsigned *word, unsigned k)
+{
+    while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void pass_turn(unsigned *word, unsigned k, int lane)
+{
+    LDS_WAVE_SYNC();
+    if (lane == 0) __hip_atomic_store(word, k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NA, int NW>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) ordered_list_kernel(RasterArgs a, BandArgs ba, int cshift)
 {
     constexpr int ESZ = edge_ints(NA);
-    extern __shared__ int band_lds[];
+    constexpr int SHORT = 16;                 // spans of up to SHORT pixels are drawn one per lane
+    extern __shared__ int row_lds[];
     if (!(a.force_order || *a.order_flag == a.order_gen)) return;
     const int W = a.W, R = ba.R;
     const int ncell = (W >> cshift) + 1;
-    int *zt = band_lds, *ct = band_lds + R * W;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    unsigned *cells = (unsigned *)(band_lds + 2 * R * W) + wv * ncell;
-    const int band = blockIdx.x;
-    if (band == 0 && t == 0) *ba.alloc = 0u;          // every list has its place by now: ready for the next batch
-    const int y0 = max(band * R, a.band_y0), y1 = min(min(band * R + R, a.H), a.band_y1);
-    if (y0 >= y1) return;
-    const int npx = (y1 - y0) * W;
-    for (int p = t; p < npx; p += 256) {
-        const size_t g = (size_t)y0 * W + p;
-        zt[p] = a.clear_pending ? INT_MAX : a.zbuf[g];
-        ct[p] = a.clear_pending ? a.clear_colour : a.cbuf[g];
+    // Workgroups go to the eight XCDs in turn, and each XCD has its own L2: the R workgroups that
+    // draw the rows of one band read the same polygon records, so they take indices that are
+    // eight apart (same XCD, started together) and share those records through one L2.
+    const int grp = blockIdx.x / (8 * R), in = blockIdx.x % (8 * R);
+    const int band = grp * 8 + in % 8, y = band * R + in / 8;
+    if (blockIdx.x == 0 && t == 0) *ba.alloc = 0u;          // every list has its place by now: ready for the next batch
+    if (band >= ba.nb) return;
+    if (y >= a.H || y < a.band_y0 || y >= a.band_y1) return;
+    int *zrow = row_lds, *crow = row_lds + W;
+    unsigned *cells = (unsigned *)(row_lds + 2 * W), *turn = cells + ncell;
+    const size_t g0 = (size_t)y * W;
+    for (int p = t; p < W; p += 64 * NW) {
+        zrow[p] = a.clear_pending ? INT_MAX : a.zbuf[g0 + p];
+        crow[p] = a.clear_pending ? a.clear_colour : a.cbuf[g0 + p];
     }
-    for (int p = lane; p < ncell; p += 64) cells[p] = ~0u;
+    for (int p = t; p < ncell + 2; p += 64 * NW) cells[p] = p < ncell ? ~0u : 0u;       // the two turn words start at 0
     __syncthreads();
 
     const unsigned long long lb = ba.base[band];
     unsigned ln = ba.total[band];
     if (lb + ln > ba.capacity) ln = ba.capacity > lb ? (unsigned)(ba.capacity - lb) : 0u;     // overflow is reported by the scan
+    const unsigned ngroups = (ln + 63u) / 64u;
     unsigned long long frags = 0;
     const int4 zero4 = make_int4(0, 0, 0, 0);
-    for (unsigned e0 = 0; e0 < ln; e0 += 64) {
-        const unsigned ei = e0 + (unsigned)lane;
-        int poly = ei < ln ? (int)ba.list[lb + ei] : -1;
+    // the list entry, header and edge coordinates of a wave's next group are fetched while it works on this one
+    auto fetch = [&](unsigned k, int &poly, int4 &h, int2 (&xy)[3]) {
+        const unsigned ei = k * 64u + (unsigned)lane;
+        poly = (k < ngroups && ei < ln) ? (int)ba.list[lb + ei] : -1;
         if ((unsigned)poly >= (unsigned)a.np) poly = -1;
-        int4 h = zero4;
-        int2 xy[3] = {make_int2(0, 0), make_int2(0, 0), make_int2(0, 0)};
+        h = zero4;
+#pragma unroll
+        for (int e = 0; e < 3; e++) xy[e] = make_int2(0, 0);
         if (poly >= 0) {
             h = *record_header(a.edges, ESZ / 4, poly);
 #pragma unroll
             for (int e = 0; e < 3; e++) xy[e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
         }
+    };
+    int poly_n;
+    int4 h_n;
+    int2 xy_n[3];
+    fetch((unsigned)wv, poly_n, h_n, xy_n);
+    for (unsigned k = (unsigned)wv; k < ngroups; k += NW) {
+        // ---- the spans of this group's polygons on the row
+        const int poly = poly_n;
+        const int4 h = h_n;
+        const int2 xy[3] = {xy_n[0], xy_n[1], xy_n[2]};
+        fetch(k + NW, poly_n, h_n, xy_n);
         const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff;
-        const int pr0 = h.x & 0xffff, pr1 = (h.x >> 16) & 0xffff;
-        for (int y = y0 + wv; y < y1; y += 4) {
-            int S[NA], E[NA], I[NA], beg = 0, end = -1;
-            bool hit = poly >= 0 && ne != 0 && y >= pr0 && y < pr1;
-            if (hit) hit = row_ends<NA>(a.edges, a.np, poly, ne, y, beg, end, S, E, xy);
+        int S[NA], E[NA], I[NA], beg = 0, end = -1;
+        bool hit = poly >= 0 && ne != 0 && y >= (h.x & 0xffff) && y < ((h.x >> 16) & 0xffff);
+        if (hit) hit = row_ends<NA>(a.edges, a.np, poly, ne, y, beg, end, S, E, xy);
 #pragma unroll
-            for (int q = 0; q < NA; q++) I[q] = 0;
-            if (hit) {
-                int span = end - beg;
-                if (span == 0) span = 1;
-                const double rs = drcp(span);
+        for (int q = 0; q < NA; q++) I[q] = 0;
+        if (hit) {
+            int span = end - beg;
+            if (span == 0) span = 1;
+            const double rs = drcp(span);
 #pragma unroll
-                for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
-                frags += (unsigned long long)(end - beg + 1);
+            for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+            frags += (unsigned long long)(end - beg + 1);
+        }
+        // A span of up to 32 pixels is one linear run of the perspective mapper (GraphicsPoly.cpp:626):
+        // its texture coordinates are start + pixel * increment, the linear mapper's form, so
+        // the run is worked out once here and the colours below know only that form.
+        int4 hc = h;
+        if (NA == 6 && hit && kind == KIND_TEX_PRP && end - beg < SHORT) {
+            prp_run(a, poly, y, beg - W / 2, end - W / 2, end - beg, S[4 % NA], S[5 % NA], I[4 % NA], I[5 % NA]);
+            hc.w = (h.w & ~0xff00) | (KIND_TEX_LIN << 8);
+        }
+        const int ckind = (hc.w >> 8) & 0xff;
+        const unsigned long long hits = __ballot(hit);
+        const bool any_long = __ballot(hit && end - beg >= SHORT) != 0ull;
+
+        const int c0 = beg >> cshift, c1 = end >> cshift;          // a short span touches at most three cells
+        // One round of the short spans in `rem`: lanes claim their cells; those that hold them all
+        // test their pixels against the row's depth values (GraphicsPoly.cpp:469-472; the values
+        // are read together, one LDS round trip, then compared and lowered) and free the cells.
+        // Returns the lanes that went; `pass` gets a bit per pixel that passed.
+        auto depth_round = [&](unsigned long long rem, unsigned &pass) -> unsigned long long {
+            const bool mine = (rem >> lane) & 1ull;
+            if (mine) {
+                atomicMin(&cells[c0], (unsigned)lane);
+                if (c1 > c0) atomicMin(&cells[c0 + 1], (unsigned)lane);
+                if (c1 > c0 + 1) atomicMin(&cells[c1], (unsigned)lane);
             }
-            const unsigned long long hits = __ballot(hit);
-            if (!hits) continue;
-            int *zrow = zt + (y - y0) * W, *crow = ct + (y - y0) * W;
-            if (__ballot(hit && end - beg >= 16) == 0ull) {
-                // ---- short spans, one per lane
-                const int c0 = beg >> cshift, c1 = end >> cshift;          // at most three cells
-                unsigned long long rem = hits;
-                while (rem) {
-                    const bool mine = (rem >> lane) & 1ull;
-                    if (mine) {
-                        atomicMin(&cells[c0], (unsigned)lane);
-                        if (c1 > c0) atomicMin(&cells[c0 + 1], (unsigned)lane);
-                        if (c1 > c0 + 1) atomicMin(&cells[c1], (unsigned)lane);
-                    }
-                    LDS_WAVE_SYNC();
-                    bool go = false;
-                    if (mine)
-                        go = cells[c0] == (unsigned)lane && (c1 <= c0 || cells[c0 + 1] == (unsigned)lane) &&
-                             (c1 <= c0 + 1 || cells[c1] == (unsigned)lane);
-                    LDS_WAVE_SYNC();
-                    if (go) {
-                        // depth tests first (GraphicsPoly.cpp:469-472), then the colours of the passes
-                        unsigned pass = 0u;
-                        int z = S[0];
-                        const int n = end - beg;
-                        for (int k = 0; k <= n; k++) {
-                            const int zi = z >> 16;
-                            if (zrow[beg + k] > zi) { zrow[beg + k] = zi; pass |= 1u << k; }
-                            z = wadd(z, I[0]);
-                        }
-                        int nb = 0;
-                        while (pass) {
-                            // up to four passes at a time: their texel loads are in flight together
-                            int kk[4];
-                            const int *tp[4];
+            LDS_WAVE_SYNC();
+            bool go = false;
+            if (mine)
+                go = cells[c0] == (unsigned)lane && (c1 <= c0 || cells[c0 + 1] == (unsigned)lane) &&
+                     (c1 <= c0 + 1 || cells[c1] == (unsigned)lane);
+            LDS_WAVE_SYNC();
+            if (go) {
+                const int n = end - beg;
+                int zo[SHORT];
 #pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                kk[q] = pass ? __ffs((int)pass) - 1 : -1;
-                                pass &= pass - 1u;            // 0 stays 0
-                                tp[q] = nullptr;
-                                if (kk[q] >= 0 && kind != KIND_FLAT) tp[q] = texel_address<NA>(a, h, poly, beg + kk[q], y, beg, end, S, I);
-                            }
-                            int src[4];
+                for (int q = 0; q < SHORT; q++) zo[q] = zrow[beg + (q <= n ? q : n)];
+                int z = S[0];
 #pragma unroll
-                            for (int q = 0; q < 4; q++) src[q] = tp[q] ? *tp[q] : h.z;
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                if (kk[q] < 0) continue;
-                                int c = h.z;
-                                if (NA > 1 && kind != KIND_FLAT) {
-                                    const int kl = kind >= KIND_TEX_LIN ? nb : kk[q];
-                                    c = cl_light(src[q], wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16,
-                                                 wadd(S[2 % NA], wmul(kl, I[2 % NA])) >> 16,
-                                                 wadd(S[3 % NA], wmul(kl, I[3 % NA])) >> 16);
-                                }
-                                crow[beg + kk[q]] = c;
-                                nb++;
-                            }
-                        }
-                        cells[c0] = ~0u;
-                        if (c1 > c0) cells[c0 + 1] = ~0u;
-                        if (c1 > c0 + 1) cells[c1] = ~0u;
-                    }
-                    LDS_WAVE_SYNC();
-                    rem &= ~__ballot(go);
+                for (int q = 0; q < SHORT; q++) {
+                    const int zi = z >> 16;
+                    if (q <= n && zo[q] > zi) { zrow[beg + q] = zi; pass |= 1u << q; }
+                    z = wadd(z, I[0]);
                 }
-            } else {
-                // ---- one polygon after the other, 64 pixels of its span per step
-                unsigned long long m = hits;
-                while (m) {
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
+                cells[c0] = ~0u;
+                if (c1 > c0) cells[c0 + 1] = ~0u;
+                if (c1 > c0 + 1) cells[c1] = ~0u;
+            }
+            LDS_WAVE_SYNC();
+            return __ballot(go);
+        };
+        // Colours of the pixels in `pass`: light has advanced once per earlier pass of the span
+        // (textured fills, GraphicsPoly.cpp:485-493), once per pixel (shaded).  Four pixels at a
+        // time, so that their texel loads are in flight together.
+        int col[SHORT];
+        auto colours = [&](unsigned pass) {
+#pragma unroll
+            for (int q = 0; q < SHORT; q++) col[q] = hc.z;
+#pragma unroll
+            for (int g = 0; g < SHORT / 4; g++) {
+                if (__ballot((pass >> (4 * g)) & 0xfu) == 0ull) continue;
+                const int *tp[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    tp[q] = nullptr;
+                    if (((pass >> (4 * g + q)) & 1u) && ckind != KIND_FLAT)
+                        tp[q] = texel_address<NA>(a, hc, poly, beg + 4 * g + q, y, beg, end, S, I);
+                }
+                int src[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) src[q] = tp[q] ? *tp[q] : hc.z;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int px = 4 * g + q;
+                    if (NA > 1 && ckind != KIND_FLAT) {
+                        const int kl = ckind >= KIND_TEX_LIN ? __popc(pass & ((1u << px) - 1u)) : px;
+                        col[px] = cl_light(src[q], wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16,
+                                           wadd(S[2 % NA], wmul(kl, I[2 % NA])) >> 16,
+                                           wadd(S[3 % NA], wmul(kl, I[3 % NA])) >> 16);
+                    }
+                }
+            }
+        };
+        auto write_colours = [&](unsigned pass) {
+#pragma unroll
+            for (int q = 0; q < SHORT; q++)
+                if ((pass >> q) & 1u) crow[beg + q] = col[q];
+        };
+
+        if (!any_long) {
+            // ---- depth tests in rounds; then the next group may start on the depth values
+            unsigned pass = 0u;
+            int my_round = -1, rounds = 0;
+            wait_turn(&turn[0], k);
+            for (unsigned long long rem = hits; rem; rounds++) {
+                const unsigned long long went = depth_round(rem, pass);
+                if ((went >> lane) & 1ull) my_round = rounds;
+                rem &= ~went;
+            }
+            pass_turn(&turn[0], k, lane);
+            // ---- colours: nothing shared is touched, the groups behind go on meanwhile
+            colours(pass);
+            // ---- colour writes in draw order: groups by turn, spans of one group by round
+            wait_turn(&turn[1], k);
+            for (int r = 0; r < rounds; r++) {
+                if (my_round == r) write_colours(pass);
+                LDS_WAVE_SYNC();
+            }
+            pass_turn(&turn[1], k, lane);
+        } else {
+            // ---- a long span in the group: after everything before it has been drawn, the short
+            // spans before the long one in rounds (colours written at once), the long span 64 pixels
+            // per step (ballot and prefix count of the passes), then on with the spans behind it
+            wait_turn(&turn[0], k);
+            wait_turn(&turn[1], k);
+            const unsigned long long longs = __ballot(hit && end - beg >= SHORT);
+            unsigned long long todo = hits;
+            while (todo) {
+                const unsigned long long lt = longs & todo;
+                const int first_long = lt ? __ffsll((long long)lt) - 1 : 64;
+                const unsigned long long sub = first_long == 64 ? todo : todo & ((1ull << first_long) - 1ull);
+                for (unsigned long long rem = sub; rem;) {
+                    unsigned pass = 0u;
+                    const unsigned long long went = depth_round(rem, pass);
+                    colours(pass);
+                    write_colours(pass);
+                    LDS_WAVE_SYNC();
+                    rem &= ~went;
+                }
+                todo &= ~sub;
+                if (first_long < 64) {
+                    const int src = first_long;
+                    todo &= ~(1ull << src);
                     const int4 bh = make_int4(__shfl(h.x, src), __shfl(h.y, src), __shfl(h.z, src), __shfl(h.w, src));
                     const int bpoly = __shfl(poly, src), bbeg = __shfl(beg, src), bend = __shfl(end, src);
                     const int bkind = (bh.w >> 8) & 0xff;
@@ -1912,15 +2015,15 @@ __global__ void __launch_bounds__(256) ordered_list_kernel(RasterArgs a, BandArg
                     for (int xb = bbeg; xb <= bend; xb += 64) {
                         const int x = xb + lane;
                         const bool in = x <= bend;
-                        const int k = x - bbeg;
-                        const int zi = wadd(bS[0], wmul(k, bI[0])) >> 16;
+                        const int kx = x - bbeg;
+                        const int zi = wadd(bS[0], wmul(kx, bI[0])) >> 16;
                         const bool pass = in && zrow[x < W ? x : W - 1] > zi;
                         const unsigned long long pm = __ballot(pass);
                         if (pass) {
                             const int nb = carry + __popcll(pm & ((1ull << lane) - 1ull));
                             int c = bh.z;
                             if (NA > 1 && bkind != KIND_FLAT)
-                                c = pixel_colour<NA>(a, bh, bpoly, x, y, bbeg, bend, bS, bI, bkind >= KIND_TEX_LIN ? nb : k);
+                                c = pixel_colour<NA>(a, bh, bpoly, x, y, bbeg, bend, bS, bI, bkind >= KIND_TEX_LIN ? nb : kx);
                             zrow[x] = zi;
                             crow[x] = c;
                         }
@@ -1929,13 +2032,14 @@ __global__ void __launch_bounds__(256) ordered_list_kernel(RasterArgs a, BandArg
                     LDS_WAVE_SYNC();
                 }
             }
+            pass_turn(&turn[0], k, lane);
+            pass_turn(&turn[1], k, lane);
         }
     }
     __syncthreads();
-    for (int p = t; p < npx; p += 256) {
-        const size_t g = (size_t)y0 * W + p;
-        a.zbuf[g] = zt[p];
-        a.cbuf[g] = ct[p];
+    for (int p = t; p < W; p += 64 * NW) {
+        a.zbuf[g0 + p] = zrow[p];
+        a.cbuf[g0 + p] = crow[p];
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) frags += __shfl_down(frags, d);
@@ -2370,18 +2474,19 @@ int ordered_band_rows(int W, int H)
     return r;
 }
 
-// Rows per band, cell size and LDS bytes of the list-driven draw-order kernel: the band's
-// depth and colour rows plus one row of cells per wave.
+// Rows per band (the granularity of the lists), cell size and LDS bytes of the list-driven
+// draw-order kernel: one row's depth and colour, the row's cells and the two turn words.
 void ordered_list_layout(int W, int H, int *R, int *cshift, size_t *lds)
 {
     *cshift = W > 8192 ? 4 : 3;
-    const size_t cells = 4 * (size_t)((W >> *cshift) + 1) * sizeof(unsigned);
-    int r = (int)((150 * 1024 - cells) / (8 * (size_t)W));
+    // bands of about 16K pixels: few enough for the bit matrix of the binning (MAX_BANDS), and most
+    // polygons of a band's list have a span on each of its rows
+    int r = (16 * 1024) / W;
     if (r < 1) r = 1;
     if (r > 16) r = 16;
     if (r > H) r = H;
     *R = r;
-    *lds = (size_t)r * W * 8 + cells;
+    *lds = (size_t)W * 8 + ((size_t)(W >> *cshift) + 1 + 2) * sizeof(unsigned);
 }
 
 bool band_lists_possible(int W, int H, int *R, int *nb)
@@ -2406,6 +2511,8 @@ static hipError_t allow_large_lds(F fn, std::atomic<bool> (&done)[MAX_DEVICES], 
     return hipSuccess;
 }
 
+constexpr int ORDERED_WAVES = 4;           // waves that share one row of the list-driven draw-order kernel
+
 // `bands` (may be null): work arrays for per-band lists; without them every band reads every header
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands)
 {
@@ -2422,7 +2529,7 @@ hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const 
     size_t lds;
     ordered_list_layout(a.W, a.H, &R, &cshift, &lds);
     if (R != bands->R) return hipErrorInvalidValue;
-    if ((e = allow_large_lds(ordered_list_kernel<6>, set_list, device)) != hipSuccess) return e;
+    if ((e = allow_large_lds(ordered_list_kernel<6, ORDERED_WAVES>, set_list, device)) != hipSuccess) return e;
     if ((e = allow_large_lds(band_bin_kernel<false>, set_count, device)) != hipSuccess) return e;
     if ((e = allow_large_lds(band_bin_kernel<true>, set_scatter, device)) != hipSuccess) return e;
     const int nchunks = (a.np + BAND_CHUNK - 1) / BAND_CHUNK;
@@ -2430,7 +2537,7 @@ hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const 
     hipLaunchKernelGGL((band_bin_kernel<false>), dim3(nchunks), dim3(256), bits, s, *bands);
     hipLaunchKernelGGL(band_scan_kernel, dim3((bands->nb + 63) / 64), dim3(1024), 0, s, *bands, nchunks);
     hipLaunchKernelGGL((band_bin_kernel<true>), dim3(nchunks), dim3(256), bits, s, *bands);
-    hipLaunchKernelGGL((ordered_list_kernel<6>), dim3(bands->nb), dim3(256), lds, s, a, *bands, cshift);
+    hipLaunchKernelGGL((ordered_list_kernel<6, ORDERED_WAVES>), dim3(((bands->nb + 7) / 8) * 8 * R), dim3(64 * ORDERED_WAVES), lds, s, a, *bands, cshift);
     return hipSuccess;
 }
 
