@@ -75,7 +75,7 @@ def measured_traffic(workload, tris, stage):
     """HBM-side bytes per launch of the stage's main kernel from the committed counter passes
     (profiles/: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this
     benchmark, KiB per launch).  Only for the workload the passes were taken on."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_c2small.json")
+    path = os.path.join(ROOT, "profiles", "r2_pmc_c2small.json")
     if workload != "c2-small" or tris != 1_000_000 or not os.path.exists(path):
         return None, None
     pmc = json.load(open(path))
@@ -96,7 +96,7 @@ def valu_roofline(workload, tris, stage, kernel_ms):
     """Second ceiling for the fill, which is bound by VALU issue: wave-instructions per launch
     (SQ_INSTS_VALU of the committed counter pass) over the kernel's measured duration, against
     1024 SIMDs issuing one wave-instruction per 4 cycles at the 2.4 GHz peak clock."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_c2small.json")
+    path = os.path.join(ROOT, "profiles", "r2_pmc_c2small.json")
     if workload != "c2-small" or tris != 1_000_000 or not os.path.exists(path) or kernel_ms <= 0:
         return None
     for name, ctrs in json.load(open(path)).items():
