@@ -240,7 +240,11 @@ int lt_shade_object(lt_ctx *ctx, const int32_t s9[9], int32_t x, int32_t y, int3
  * (x1, y1) with depth z1: drawn if on the screen and nearer than the depth buffer; 2 G_pixel
  * (:117-123) at (x1, y1): written without a depth test (off the screen it is dropped; the
  * reference would write outside its buffer).  Neither looks at the clip window, as in the
- * reference.  The device array must be 16-byte aligned. */
+ * reference.  3 a line that the caller has already clipped: its end points, depths included,
+ * are taken as they are (both must lie on the screen, else the line is dropped and lt_flush
+ * reports LT_ERR_OVERFLOW) -- for a caller that reproduces the reference's stale depth of
+ * clipped end points itself, as the host mirror does with HW_track_clipper_stores.
+ * The device array must be 16-byte aligned. */
 int lt_submit_lines_dev(lt_ctx *ctx, const int32_t *d_lines, int n);
 int lt_submit_lines(lt_ctx *ctx, const int32_t *lines, int n);
 

@@ -2571,10 +2571,13 @@ __device__ __forceinline__ bool clip_line_xy(Tup<3> &v1, Tup<3> &v2, int bmin, i
 // into colours.  Points outside rows [by0, by1) belong to another context's band.
 __device__ __forceinline__ void draw_line(int W, const ClipWindow cw, int by0, int by1, const int *__restrict__ zbuf,
                                           unsigned *winner, Tup<3> v1, Tup<3> v2, unsigned id, unsigned long long &tests,
-                                          bool &bad)
+                                          bool &bad, bool clipped = false)
 {
-    if (!clip_line_xy<0>(v1, v2, cw.x0, cw.x1, bad)) return;
-    if (!clip_line_xy<1>(v1, v2, cw.y0, cw.y1, bad)) return;
+    // `clipped`: the caller has clipped the line (and chosen the depth of its end points)
+    if (!clipped) {
+        if (!clip_line_xy<0>(v1, v2, cw.x0, cw.x1, bad)) return;
+        if (!clip_line_xy<1>(v1, v2, cw.y0, cw.y1, bad)) return;
+    }
     if (bad) return;
     int dx = v2.v[0] - v1.v[0], dy = v2.v[1] - v1.v[1];
     const int sx = dx < 0 ? -1 : 1, sy = dy < 0 ? -1 : 1;
@@ -2716,7 +2719,7 @@ __global__ void __launch_bounds__(128) wire_kernel(SetupArgs a, const int *__res
 }
 
 // G_line for n lines in draw order: lines[i] = {x1, y1, z1, x2, y2, z2, lit colour, kind}; kind 1 and
-// 2 are G_dot and G_pixel at (x1, y1, z1)
+// 2 are G_dot and G_pixel at (x1, y1, z1), kind 3 a line whose ends are final (clipped by the caller)
 __global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ lines, int n, int W, int H, ClipWindow cw, int by0, int by1,
                                                     const int *__restrict__ zbuf, unsigned *winner, Status *status)
 {
@@ -2731,6 +2734,11 @@ __global__ void __launch_bounds__(128) lines_kernel(const int *__restrict__ line
         const int kind = hi.w;
         if (kind == 0) {
             draw_line(W, cw, by0, by1, zbuf, winner, v1, v2, (unsigned)i + 1u, tests, bad);
+        } else if (kind == 3) {
+            // a line that its caller has clipped: both ends must be on the screen
+            if ((unsigned)lo.x < (unsigned)W && (unsigned)lo.y < (unsigned)H && (unsigned)lo.w < (unsigned)W && (unsigned)hi.x < (unsigned)H)
+                draw_line(W, cw, by0, by1, zbuf, winner, v1, v2, (unsigned)i + 1u, tests, bad, true);
+            else bad = true;
         } else if ((unsigned)lo.x < (unsigned)W && (unsigned)lo.y < (unsigned)H && lo.y >= by0 && lo.y < by1) {
             // G_dot (GraphicsBase.cpp:133-153): on the screen and nearer than the depth buffer;
             // G_pixel (:117-123): no test at all (a pixel off the screen is dropped here, the

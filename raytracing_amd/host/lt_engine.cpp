@@ -29,6 +29,7 @@ int g_device = 0;
 lt_ctx *g_ctx = nullptr;
 int g_rendering_type = 0;
 bool g_host_frame_current = false;
+bool g_track_stores = false;                         // HW_track_clipper_stores
 
 int T_sin_tab[256], T_cos_tab[256];
 int Ts[9], Tw[9], Tc[12];                            // self / world rotation, concatenated transform
@@ -228,6 +229,8 @@ void G_clear(HW_pixel colour, int red, int green, int blue)
     g_host_frame_current = false;
 }
 
+static void track_fill(int *edges, int length, int xdim, int ydim);
+
 static void queue_screen(int type, int dim, int *edges, int length, HW_pixel colour, int tex)
 {
     need_ctx();
@@ -237,6 +240,7 @@ static void queue_screen(int type, int dim, int *edges, int length, HW_pixel col
     q_desc.insert(q_desc.end(), d, d + 4);
     q_tuples.insert(q_tuples.end(), edges, edges + (length + 1) * dim);
     if (length > q_max_edges) q_max_edges = length;
+    if (g_track_stores) track_fill(edges, length, dim, type == LT_TEXTURED_PRP ? G_LNG_SHADED : dim);
 }
 
 // GraphicsPoly.cpp:520-684; M_camera_log_focus is read at the time of the call, as the
@@ -256,6 +260,16 @@ void G_prp_textured_polygon(int *edges, int length, int *O, int *u, int *v, HW_p
 void G_line(int *vertex1, int *vertex2, HW_pixel colour, int red, int green, int blue)
 {
     need_ctx();
+    if (g_track_stores) {
+        // GraphicsBase.cpp:191-193 on the host: the two clips with dimension 2 hand back pointers into
+        // the clippers' static stores, whose third word is whatever earlier calls left there
+        int *v1 = vertex1, *v2 = vertex2;
+        if (!C_line_x_clipping(&v1, &v2, 2) || !C_line_y_clipping(&v1, &v2, 2)) return;
+        open_queue(Q_LINES, 0);
+        const int32_t l[8] = {v1[0], v1[1], v1[2], v2[0], v2[1], v2[2], CL_light(colour, red, green, blue), 3};
+        q_lines.insert(q_lines.end(), l, l + 8);
+        return;
+    }
     open_queue(Q_LINES, 0);
     const int32_t l[8] = {vertex1[0], vertex1[1], vertex1[2], vertex2[0], vertex2[1], vertex2[2],
                           CL_light(colour, red, green, blue), 0};
@@ -507,6 +521,68 @@ int T_normal_z_negative(int *from1, int *from2, int *from3)
 
 // ------------------------------------------------------------------ engine (EngBase.cpp / EngPoly.cpp)
 
+// ---- the clippers' static stores (HW_track_clipper_stores)
+//
+// G_line clips with dimension 2 (GraphicsBase.cpp:191-193), so the depth of a clipped end point
+// is the third word of one of the 2-D clippers' static stores (Clipp2D.cpp:99-104, 172-177):
+// a leftover of the last polygon clips.  With tracking on, every polygon that is drawn makes
+// the reference's own sequence of clipper calls on the host as well (their results are
+// dropped: the GPU clips for itself), so that the stores hold what the reference's would, and
+// G_line clips on the host and reads them.
+
+void HW_track_clipper_stores(int on)
+{
+    if (g_ctx) run_queue();
+    g_track_stores = on != 0;
+}
+
+// G_*_polygon up to the edge scan: C_polygon_x_clipping, then GI_scan's y clip of every edge
+// (GraphicsPoly.cpp:318-323, 136; the perspective mapper scans with the shaded dimension, :559)
+static void track_fill(int *edges, int length, int xdim, int ydim)
+{
+    int out[64 * LT_C_MAX_DIMENSIONS];
+    if (length + 1 > 16) return;
+    const int n = C_polygon_x_clipping(edges, out, xdim, length);
+    for (int i = 0; i < n && i < 62; i++) {
+        int *v1 = out + i * xdim, *v2 = v1 + xdim;
+        C_line_y_clipping(&v1, &v2, ydim);
+    }
+}
+
+// M_render_polygon (EngBase.cpp:379-552) as far as its clipper calls go.  `wire`: draw the edges
+// (the M_WIRE case is drawn from here when tracking is on, one G_line per edge).
+static void track_view_polygon(const M_polygon *poly, const int *vertices, const int *colours, const int *textures, int type)
+{
+    const int e = poly->m_no_edges;
+    if (e < 2 || e + 1 > 16) return;
+    const bool textured = type == M_TEXTURED && poly->m_texture != nullptr;
+    const int dim = (type == M_WIRE || type == M_FLAT) ? 3 : (textured ? 8 : 6);
+    int orig[17 * 8], clip[64 * 8], persp[64 * 8];
+    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    for (int k = 0; k <= e; k++) {                  // CI_construct_tuples, EngBase.cpp:47-138
+        const int *r = poly->m_vertices + k * M_LNG_POLYGON_VERTEX;
+        const int *v = vertices + (size_t)r[0] * T_LNG_VECTOR;
+        int *t = orig + k * dim;
+        for (int q = 0; q < 3; q++) { t[q] = v[q]; mn[q] = v[q] < mn[q] ? v[q] : mn[q]; mx[q] = v[q] > mx[q] ? v[q] : mx[q]; }
+        if (dim >= 6) for (int q = 0; q < 3; q++) t[3 + q] = (int)((unsigned)(colours ? colours[(size_t)r[0] * 3 + q] : r[1 + q]) << 16);
+        if (dim == 8) for (int q = 0; q < 2; q++) t[6 + q] = (int)((unsigned)(textures ? textures[(size_t)r[0] * 2 + q] : r[4 + q]) << 16);
+    }
+    const int cnd = C_volume_clipping(mn, mx);
+    if (cnd == 0) return;
+    int number = e;
+    int *clipped = orig;
+    if (cnd == -1) { number = C_polygon_z_clipping(orig, clip, dim, number); clipped = clip; }
+    if (number + 1 > 60) return;
+    T_perspective(clipped, persp, dim, number + 1, M_camera_log_focus);
+    if (!T_normal_z_negative(persp, persp + dim, persp + 2 * dim)) return;
+    if (type == M_WIRE) {
+        for (int i = 0; i < number; i++) G_line(persp + i * dim, persp + (i + 1) * dim, poly->m_colour, poly->m_red, poly->m_green, poly->m_blue);
+        return;
+    }
+    const bool prp = textured && (M_force_linear_tmapping || clipped[2] < G_Z_MAPPING_SWITCH);
+    track_fill(persp, number, dim, prp ? G_LNG_SHADED : dim);
+}
+
 void M_init_rendering(int type) { g_rendering_type = type; }
 
 void M_set_camera(unsigned char alp, unsigned char bet, unsigned char gam, int x, int y, int z, int log_focus)
@@ -530,6 +606,10 @@ void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *
 {
     need_ctx();
     const int type = lt_type();
+    if (g_track_stores) {
+        track_view_polygon(poly, vertices, colours, textures, type);
+        if (type == M_WIRE) return;                  // drawn as host-clipped lines
+    }
     open_queue(Q_VIEW, type);
     const int base = (int)(q_verts.size() / 4);
     M_polygon tmp = *poly;
@@ -929,6 +1009,14 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
     g_host_frame_current = false;
     T_set_self_rotation((unsigned char)alp, (unsigned char)bet, (unsigned char)gam);
     T_cancatinate_self_world(x + M_camera_x, y + M_camera_y, z + M_camera_z);
+    if (g_track_stores) {
+        // the transform on the host too, for the clipper calls of every polygon (EngPoly.cpp:512-523);
+        // a wireframe object is drawn from there, as host-clipped lines
+        std::vector<int> tmp((size_t)object->m_no_vertices * T_LNG_VECTOR);
+        T_cancatinated_rotation(object->m_vertices, tmp.data(), object->m_no_vertices);
+        for (int i = 0; i < object->m_no_polygons; i++) track_view_polygon(object->m_polygons[i], tmp.data(), nullptr, nullptr, type);
+        if (type == M_WIRE) return;
+    }
     std::vector<int32_t> polys, aux, pv;
     int me = 0;
     for (int i = 0; i < object->m_no_polygons; i++) {

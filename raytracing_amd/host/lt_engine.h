@@ -26,7 +26,13 @@ int HW_screen_x_size(void);
 int HW_screen_y_size(void);
 void HW_error(char *s, ...);                // prints and terminates (weak: a harness may replace it)
 void HW_flush(void);                        // run queued draws, bring the frame to G_c_buffer / G_z_buffer
-void HW_select_device(int device);          // before G_init_graphics; default 0
+void HW_select_device(int device);
+// G_line clips with dimension 2, so the depth of a clipped end point is a leftover of earlier
+// clipper calls (Clipp2D.cpp:99-104).  on: every polygon drawn also makes the reference's
+// clipper calls on the host and G_line clips there, so that a clipped line drawn after filled
+// polygons gets the depth the reference reads (host work per polygon).  off (default): a
+// clipped end point takes depth 0, the value in a program that draws only wireframes.
+void HW_track_clipper_stores(int on);          // before G_init_graphics; default 0
 
 // ---- Colour.h:140-148
 void CL_init_colour(void);

@@ -212,4 +212,6 @@ void lte_g_prp_polygon(int *tuples, int length, int *O, int *u, int *v, int tex,
     G_prp_textured_polygon(tuples, length, O, u, v, g_texs[tex].m_texture_bytes, g_texs[tex].m_log_texture_size, log_scale);
 }
 
+void lte_track_clipper_stores(int on) { HW_track_clipper_stores(on); }
+
 }  // extern "C"

@@ -13,6 +13,8 @@ and expected outputs -- stored as .npz (no pickles) and .json next to this scrip
   c1_scene.npz      configuration 1: the tracer.dat world (quad + three spheres, tessellated
                     and lit by this script) as flat scene arrays, with the reference's frame
   crops.npz         a few raw 32x32 crops of reference frames
+  stale_depth_kats.json  frames with screen-clipped lines drawn after filled polygons (their end
+                    points' depth is a leftover in the clippers' static stores)
   prp_kats.json     frames of G_prp_textured_polygon calls (the perspective mapper at the G_* level)
   c4_frames.json    configuration 4: digests of four frames of the animated 1M-triangle batch
   c5_frame.json     configuration 5 in shape: digests of one 16384 x 16384 frame of 1M triangles
@@ -520,6 +522,45 @@ def bench_frame():
                 depth=S.frame_digest(z), drawn_pixels=int((z != 2 ** 31 - 1).sum()))
 
 
+def stale_depth_cases():
+    """Frames in which lines that the screen clips are drawn AFTER filled polygons: G_line clips with
+    dimension 2 (GraphicsBase.cpp:191-193), so a clipped end point's depth is what the polygon
+    clips before it left in the clippers' static stores (Clipp2D.cpp:99-104).  Every case starts
+    with an object of many clipped polygons, which overwrites every store: the frames do not
+    depend on what ran before.  Steps as in wire_cases."""
+    w, h = WIRE_W, WIRE_H
+    cases = {}
+    a = S.gen_fuzz_polys(180, w, h, 7, 9100, render_type=S.M_SHADED)
+    b = S.gen_fuzz_polys(120, w, h, 7, 9101, render_type=S.M_FLAT)
+    cases["shaded_flat_lines"] = [("clear", 0x101820), ("object", a, S.M_SHADED, (3, 4, 5, 0, 0, 30)),
+                                  ("lines", wire_lines(9110, 300, -150, 200, -30000, -300)),
+                                  ("object", b, S.M_FLAT, (250, 2, 9, 4, -3, 25)),
+                                  ("lines", wire_lines(9111, 200, -90, 120, -30000, -300))]
+    t = S.gen_fuzz_polys(160, w, h, 7, 9102, render_type=S.M_TEXTURED, textured=True, equal_lights=True, zrange=(12, 2000))
+    wsc = S.gen_fuzz_polys(140, w, h, 7, 9103, render_type=S.M_FLAT)
+    cases["textured_wire_object"] = [("clear", 0x000030), ("object", t, S.M_TEXTURED, (1, 2, 3, 0, 0, 20)),
+                                     ("object", wsc, S.M_WIRE, (3, 4, 5, 0, 0, 30)),
+                                     ("lines", wire_lines(9112, 250, -200, 250, -40000, -200)),
+                                     ("object", a, S.M_SHADED, (9, 250, 3, -5, 2, 40)),
+                                     ("object", wsc, S.M_WIRE, (250, 7, 1, 6, 0, 12))]
+    g = S.gen_screen_polys(90, w, h, seed=9104, dim=6)
+    cases["screen_polys_lines"] = [("clear", 0), ("object", a, S.M_SHADED, (3, 4, 5, 0, 0, 30)), ("gpolys", 4, g),
+                                   ("lines", wire_lines(9113, 300, -120, 150, -50000, 50))]
+    return cases
+
+
+def stale_depth_kats():
+    """stale_depth_cases() drawn by the reference build: digests."""
+    out = {}
+    for name, steps in stale_depth_cases().items():
+        r = R.Ref(WIRE_W, WIRE_H)
+        for hnd, (tex, lg) in enumerate(_textures_of(steps)):
+            r.set_texture(hnd, tex, lg)
+        c, z = run_wire_case(steps, r)
+        out[name] = dict(colour=S.frame_digest(c), depth=S.frame_digest(z), drawn=int((c != c[0, 0]).sum()))
+    return out
+
+
 def prp_cases():
     """Frames of G_prp_textured_polygon calls at WIRE_W x WIRE_H, log_focus 7, texture
     make_texture(9, 6): name -> list of (length, tuples int32[length+1][8], O int32[8], u int32[3],
@@ -603,6 +644,9 @@ def c5_frame():
 
 
 def main():
+    if "--stale" in sys.argv:
+        json.dump(stale_depth_kats(), open(os.path.join(HERE, "stale_depth_kats.json"), "w"), indent=1, sort_keys=True)
+        return
     if "--prp" in sys.argv:
         json.dump(prp_kats(), open(os.path.join(HERE, "prp_kats.json"), "w"), indent=1, sort_keys=True)
         return
@@ -617,6 +661,7 @@ def main():
     json.dump(wire_kats(), open(os.path.join(HERE, "wire_kats.json"), "w"), indent=1, sort_keys=True)
     json.dump(window_kats(), open(os.path.join(HERE, "window_kats.json"), "w"), indent=1, sort_keys=True)
     json.dump(prp_kats(), open(os.path.join(HERE, "prp_kats.json"), "w"), indent=1, sort_keys=True)
+    json.dump(stale_depth_kats(), open(os.path.join(HERE, "stale_depth_kats.json"), "w"), indent=1, sort_keys=True)
     np.savez_compressed(os.path.join(HERE, "gate_kats.npz"), **gate_kats())
     np.savez_compressed(os.path.join(HERE, "bicubic_kats.npz"), **bicubic_kats())
     if not os.path.isdir(REFDIR):
