@@ -785,8 +785,10 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
 //
 // SCREEN = true starts at the X stage with already-projected tuples (the G_*_polygon
 // entry points); polys[] then holds {first, length, colour, tex} descriptors.
+// `first_known` (screen mode, >= 0): the polygon's first tuple, where the caller can tell it
+// without the descriptor, so that descriptor and tuples are fetched together.
 template <int DIM, bool SCREEN>
-__device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, const int slot)
+__device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, const int slot, const int first_known = -1)
 {
     constexpr int NA = DIM - 2;
     constexpr int ESZ = edge_ints(NA);
@@ -795,7 +797,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
 
     const int4 pd = ((const int4 *)a.polys)[poly];
     int colour, tex, e, first;
-    if (SCREEN) { first = pd.x; e = pd.y & 0xff; colour = pd.z; tex = pd.w; }
+    if (SCREEN) { first = first_known >= 0 ? first_known : pd.x; e = pd.y & 0xff; colour = pd.z; tex = pd.w; }
     else        { colour = pd.x; tex = pd.y; e = pd.z; first = pd.w; }
 
     bool bad = false;        // polygon cannot be processed (limits); counted, not drawn
@@ -1151,8 +1153,11 @@ __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_kernel(SetupArg
         q.use_matrix = 0;
         const unsigned cnt = min(a.sq_count[blockIdx.y * QUEUE_COUNT_STRIDE], a.queue_cap);
         for (unsigned qi = blockIdx.x * blockDim.x + threadIdx.x; qi < cnt; qi += gridDim.x * blockDim.x) {
-            const uint2 e = a.sq_queue[(size_t)blockIdx.y * a.queue_cap + qi];
-            if (e.x < q.queue_index_limit && e.y < (unsigned)a.np) setup_one<DIM, true>(q, (int)e.x, (int)e.y);
+            // entry i of the screen queue describes itself (the fast kernel wrote {i, slot}, descriptor i
+            // and tuples 4i ..): the slot, the descriptor and the tuples are fetched together
+            const unsigned idx = blockIdx.y * a.queue_cap + qi;
+            const uint2 e = a.sq_queue[idx];
+            if (idx < q.queue_index_limit && e.y < (unsigned)a.np) setup_one<DIM, true>(q, (int)idx, (int)e.y, (int)(idx * 4u));
         }
     } else {
         const unsigned y = blockIdx.y - QUEUES;

@@ -129,6 +129,8 @@ struct Loader {
         case T_LSQ: {
             if (next() != T_INT) die("Number expected");
             const int n = tok_int;
+            // the reference takes any count; a file is not trusted with more than this many elements
+            if (n < 0 || n > (1 << 24)) die("Number expected");
             if (next() != T_RSQ) die("Closing bracket expected");
             Type t;
             t.base = B_ARRAY; t.count = n;
