@@ -1685,46 +1685,50 @@ constexpr int BAND_WORDS = BAND_CHUNK / 32;
 constexpr int BAND_PITCH = BAND_WORDS + 1;       // LDS words between two bands' rows (bank spread)
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) band_bin_kernel(BandArgs a)
+__global__ void __launch_bounds__(256) band_bin_kernel(BandArgs a, int nchunks)
 {
     extern __shared__ unsigned band_bits[];
     if (!(a.force_order || *a.order_flag == a.order_gen)) return;
     const int t = threadIdx.x;
-    for (int i = t; i < a.nb * BAND_PITCH; i += 256) band_bits[i] = 0u;
-    __syncthreads();
-    const int chunk = blockIdx.x;
+    // The grid is capped (the bit matrix is large: few workgroups fit a CU) and strides over the
+    // chunks, so a batch that is not filled in draw order costs a few hundred empty workgroups.
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        for (int i = t; i < a.nb * BAND_PITCH; i += 256) band_bits[i] = 0u;
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < BAND_CHUNK / 256; k++) {
-        const int idx = k * 256 + t, slot = chunk * BAND_CHUNK + idx;
-        if (slot < a.np) {
-            const int4 h = ((const int4 *)a.hdr)[slot];
-            if ((h.w & 0xff) != 0) {
-                const int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff;
-                const int b0 = miny / a.R, b1 = min((maxy - 1) / a.R, a.nb - 1);
-                for (int b = b0; b <= b1; b++) atomicOr(&band_bits[b * BAND_PITCH + (idx >> 5)], 1u << (idx & 31));
-            }
-        }
-    }
-    __syncthreads();
-    for (int b = t; b < a.nb; b += 256) {
-        const unsigned *row = band_bits + b * BAND_PITCH;
-        if (!SCATTER) {
-            unsigned c = 0;
-#pragma unroll 8
-            for (int k = 0; k < BAND_WORDS; k++) c += __popc(row[k]);
-            a.cnt[(size_t)chunk * a.nb + b] = c;
-        } else {
-            unsigned long long pos = (unsigned long long)a.base[b] + a.cnt[(size_t)chunk * a.nb + b];
-            for (int k = 0; k < BAND_WORDS; k++) {
-                unsigned w = row[k];
-                while (w) {
-                    const int bit = __ffs((int)w) - 1;
-                    w &= w - 1;
-                    if (pos < a.capacity) a.list[pos] = (unsigned)(chunk * BAND_CHUNK + k * 32 + bit);
-                    pos++;
+        for (int k = 0; k < BAND_CHUNK / 256; k++) {
+            const int idx = k * 256 + t, slot = chunk * BAND_CHUNK + idx;
+            if (slot < a.np) {
+                const int4 h = ((const int4 *)a.hdr)[slot];
+                if ((h.w & 0xff) != 0) {
+                    const int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff;
+                    const int b0 = miny / a.R, b1 = min((maxy - 1) / a.R, a.nb - 1);
+                    for (int b = b0; b <= b1; b++) atomicOr(&band_bits[b * BAND_PITCH + (idx >> 5)], 1u << (idx & 31));
                 }
             }
         }
+        __syncthreads();
+        for (int b = t; b < a.nb; b += 256) {
+            const unsigned *row = band_bits + b * BAND_PITCH;
+            if (!SCATTER) {
+                unsigned c = 0;
+#pragma unroll 8
+                for (int k = 0; k < BAND_WORDS; k++) c += __popc(row[k]);
+                a.cnt[(size_t)chunk * a.nb + b] = c;
+            } else {
+                unsigned long long pos = (unsigned long long)a.base[b] + a.cnt[(size_t)chunk * a.nb + b];
+                for (int k = 0; k < BAND_WORDS; k++) {
+                    unsigned w = row[k];
+                    while (w) {
+                        const int bit = __ffs((int)w) - 1;
+                        w &= w - 1;
+                        if (pos < a.capacity) a.list[pos] = (unsigned)(chunk * BAND_CHUNK + k * 32 + bit);
+                        pos++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -2517,6 +2521,7 @@ static hipError_t allow_large_lds(F fn, std::atomic<bool> (&done)[MAX_DEVICES], 
 }
 
 constexpr int ORDERED_WAVES = 4;           // waves that share one row of the list-driven draw-order kernel
+constexpr int BAND_BIN_MAX_GRID = 1024;    // workgroups of the band binning (they stride over the chunks)
 
 // `bands` (may be null): work arrays for per-band lists; without them every band reads every header
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands)
@@ -2539,9 +2544,10 @@ hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const 
     if ((e = allow_large_lds(band_bin_kernel<true>, set_scatter, device)) != hipSuccess) return e;
     const int nchunks = (a.np + BAND_CHUNK - 1) / BAND_CHUNK;
     const size_t bits = (size_t)bands->nb * BAND_PITCH * sizeof(unsigned);
-    hipLaunchKernelGGL((band_bin_kernel<false>), dim3(nchunks), dim3(256), bits, s, *bands);
+    const int bin_grid = nchunks < BAND_BIN_MAX_GRID ? nchunks : BAND_BIN_MAX_GRID;
+    hipLaunchKernelGGL((band_bin_kernel<false>), dim3(bin_grid), dim3(256), bits, s, *bands, nchunks);
     hipLaunchKernelGGL(band_scan_kernel, dim3((bands->nb + 63) / 64), dim3(1024), 0, s, *bands, nchunks);
-    hipLaunchKernelGGL((band_bin_kernel<true>), dim3(nchunks), dim3(256), bits, s, *bands);
+    hipLaunchKernelGGL((band_bin_kernel<true>), dim3(bin_grid), dim3(256), bits, s, *bands, nchunks);
     hipLaunchKernelGGL((ordered_list_kernel<6, ORDERED_WAVES>), dim3(((bands->nb + 7) / 8) * 8 * R), dim3(64 * ORDERED_WAVES), lds, s, a, *bands, cshift);
     return hipSuccess;
 }
