@@ -1816,6 +1816,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
 {
     constexpr int ESZ = edge_ints(NA);
     constexpr int SHORT = 16;                 // spans of up to SHORT pixels are drawn one per lane
+    constexpr int LONG_PRE = 4;               // chunks of long spans whose colours are worked out before the colour turn
     extern __shared__ int row_lds[];
     if (!(a.force_order || *a.order_flag == a.order_gen)) return;
     const int W = a.W, R = ba.R;
@@ -1831,12 +1832,22 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
     if (y >= a.H || y < a.band_y0 || y >= a.band_y1) return;
     int *zrow = row_lds, *crow = row_lds + W;
     unsigned *cells = (unsigned *)(row_lds + 2 * W), *turn = cells + ncell;
+    int *zcoarse = (int *)(turn + 2);           // largest depth of each aligned 64-pixel chunk of the row (never too small)
+    const int nchunk = (W + 63) >> 6;
     const size_t g0 = (size_t)y * W;
     for (int p = t; p < W; p += 64 * NW) {
         zrow[p] = a.clear_pending ? INT_MAX : a.zbuf[g0 + p];
         crow[p] = a.clear_pending ? a.clear_colour : a.cbuf[g0 + p];
     }
     for (int p = t; p < ncell + 2; p += 64 * NW) cells[p] = p < ncell ? ~0u : 0u;       // the two turn words start at 0
+    __syncthreads();
+    for (int ch = wv; ch < nchunk; ch += NW) {
+        const int x = (ch << 6) + lane;
+        int m = x < W ? zrow[x] : INT_MIN;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
+        if (lane == 0) zcoarse[ch] = m;
+    }
     __syncthreads();
 
     const unsigned long long lb = ba.base[band];
@@ -1893,7 +1904,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
         }
         const int ckind = (hc.w >> 8) & 0xff;
         const unsigned long long hits = __ballot(hit);
-        const bool any_long = __ballot(hit && end - beg >= SHORT) != 0ull;
+        const unsigned long long longs = __ballot(hit && end - beg >= SHORT);
 
         const int c0 = beg >> cshift, c1 = end >> cshift;          // a short span touches at most three cells
         // One round of the short spans in `rem`: lanes claim their cells; those that hold them all
@@ -1970,80 +1981,171 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
                 if ((pass >> q) & 1u) crow[beg + q] = col[q];
         };
 
-        if (!any_long) {
-            // ---- depth tests in rounds; then the next group may start on the depth values
-            unsigned pass = 0u;
-            int my_round = -1, rounds = 0;
-            wait_turn(&turn[0], k);
-            for (unsigned long long rem = hits; rem; rounds++) {
-                const unsigned long long went = depth_round(rem, pass);
-                if ((went >> lane) & 1ull) my_round = rounds;
-                rem &= ~went;
-            }
-            pass_turn(&turn[0], k, lane);
-            // ---- colours: nothing shared is touched, the groups behind go on meanwhile
-            colours(pass);
-            // ---- colour writes in draw order: groups by turn, spans of one group by round
-            wait_turn(&turn[1], k);
-            for (int r = 0; r < rounds; r++) {
-                if (my_round == r) write_colours(pass);
+        // ---- depth phase, in draw order, under the row's depth turn.  Short spans go in rounds
+        // (sequence number `seq` per round); a long span is swept in 64-pixel chunks aligned to the
+        // row: a coarse table (largest depth of each chunk) rejects whole chunks, the others are
+        // tested a pixel per lane.  Nothing is coloured here: a short span keeps its pass mask, a
+        // chunk of a long span with passes is recorded in the registers of lane `nent` (chunk
+        // start, source lane and sequence number, passes before the chunk, pass mask).
+        int ent_xb = 0, ent_tag = 0, ent_carry = 0;
+        unsigned ent_lo = 0u, ent_hi = 0u;
+        int nent = 0, seq = 0, my_seq = -1;
+        unsigned pass = 0u;
+        unsigned long long long_seqs = 0ull;          // bit s: sequence number s is a long span
+        bool immediate = false;                       // colours written at once, both turns held
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        auto RL = [&](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+        // a long span's data, read from the lane that holds it (wave-uniform values), and the
+        // colour of its pixel x after `nbk` earlier passes
+        struct Span { int4 h; int poly, beg, end; int S[NA], I[NA]; };
+        auto span_of = [&](int src) -> Span {
+            Span sp;
+            sp.h = make_int4(RL(h.x, src), RL(h.y, src), RL(h.z, src), RL(h.w, src));
+            sp.poly = RL(poly, src); sp.beg = RL(beg, src); sp.end = RL(end, src);
+#pragma unroll
+            for (int q = 0; q < NA; q++) { sp.S[q] = RL(S[q], src); sp.I[q] = RL(I[q], src); }
+            return sp;
+        };
+        auto span_colour = [&](const Span &sp, int x, int nbk) -> int {
+            const int bkind = (sp.h.w >> 8) & 0xff;
+            if (NA == 1 || bkind == KIND_FLAT) return sp.h.z;
+            return pixel_colour<NA>(a, sp.h, sp.poly, x, y, sp.beg, sp.end, sp.S, sp.I, bkind >= KIND_TEX_LIN ? nbk : x - sp.beg);
+        };
+        int lcol[LONG_PRE];
+        // colour writes of everything recorded so far, in sequence order (under the colour turn)
+        auto flush = [&](bool pre) {
+            int e = 0;
+            for (int sq = 0; sq < seq; sq++) {
+                if ((long_seqs >> sq) & 1ull) {
+                    while (e < nent) {
+                        const int tag = RL(ent_tag, e);
+                        if ((tag >> 8) != sq) break;
+                        const unsigned long long pm = (unsigned long long)(unsigned)RL((int)ent_lo, e) |
+                                                      ((unsigned long long)(unsigned)RL((int)ent_hi, e) << 32);
+                        const int xb = RL(ent_xb, e), cr = RL(ent_carry, e);
+                        if (pre && e < LONG_PRE) {
+                            int c = 0;
+#pragma unroll
+                            for (int q = 0; q < LONG_PRE; q++) c = e == q ? lcol[q] : c;
+                            if ((pm >> lane) & 1ull) crow[xb + lane] = c;
+                        } else {
+                            const Span sp = span_of(tag & 0xff);
+                            if ((pm >> lane) & 1ull) crow[xb + lane] = span_colour(sp, xb + lane, cr + __popcll(pm & lt_mask));
+                        }
+                        e++;
+                    }
+                } else if (my_seq == sq) {
+                    write_colours(pass);
+                }
                 LDS_WAVE_SYNC();
             }
-            pass_turn(&turn[1], k, lane);
-        } else {
-            // ---- a long span in the group: after everything before it has been drawn, the short
-            // spans before the long one in rounds (colours written at once), the long span 64 pixels
-            // per step (ballot and prefix count of the passes), then on with the spans behind it
-            wait_turn(&turn[0], k);
+        };
+        // more long spans or rounds than the records hold: take the colour turn as well, write what
+        // is pending, and draw the rest of the group with its colours at once
+        auto go_immediate = [&]() {
             wait_turn(&turn[1], k);
-            const unsigned long long longs = __ballot(hit && end - beg >= SHORT);
-            unsigned long long todo = hits;
-            while (todo) {
-                const unsigned long long lt = longs & todo;
-                const int first_long = lt ? __ffsll((long long)lt) - 1 : 64;
-                const unsigned long long sub = first_long == 64 ? todo : todo & ((1ull << first_long) - 1ull);
-                for (unsigned long long rem = sub; rem;) {
-                    unsigned pass = 0u;
-                    const unsigned long long went = depth_round(rem, pass);
-                    colours(pass);
-                    write_colours(pass);
+            colours(pass);
+            flush(false);
+            immediate = true;
+            pass = 0u; my_seq = -1; nent = 0; seq = 0; long_seqs = 0ull;
+        };
+
+        wait_turn(&turn[0], k);
+        unsigned long long todo = hits;
+        while (todo) {
+            const unsigned long long ltd = longs & todo;
+            const int first_long = ltd ? __ffsll((long long)ltd) - 1 : 64;
+            const unsigned long long sub = first_long == 64 ? todo : todo & ((1ull << first_long) - 1ull);
+            for (unsigned long long rem = sub; rem;) {
+                if (!immediate && seq >= 63) go_immediate();
+                unsigned long long went;
+                if (!immediate) {
+                    went = depth_round(rem, pass);
+                    if ((went >> lane) & 1ull) my_seq = seq;
+                    seq++;
+                } else {
+                    unsigned p1 = 0u;
+                    went = depth_round(rem, p1);
+                    colours(p1);
+                    write_colours(p1);
                     LDS_WAVE_SYNC();
-                    rem &= ~went;
                 }
-                todo &= ~sub;
-                if (first_long < 64) {
-                    const int src = first_long;
-                    todo &= ~(1ull << src);
-                    const int4 bh = make_int4(__shfl(h.x, src), __shfl(h.y, src), __shfl(h.z, src), __shfl(h.w, src));
-                    const int bpoly = __shfl(poly, src), bbeg = __shfl(beg, src), bend = __shfl(end, src);
-                    const int bkind = (bh.w >> 8) & 0xff;
-                    int bS[NA], bI[NA];
+                rem &= ~went;
+            }
+            todo &= ~sub;
+            if (first_long < 64) {
+                const int src = first_long;
+                todo &= ~(1ull << src);
+                if (!immediate && seq >= 63) go_immediate();
+                const Span sp = span_of(src);
+                const int bbeg = sp.beg, bend = sp.end, bS0 = sp.S[0], bI0 = sp.I[0];
+                // without a 32-bit wrap along the span the depth runs monotonically: a chunk's
+                // smallest depth is at one of its ends
+                const long long zlast = (long long)bS0 + (long long)(bend - bbeg) * bI0;
+                const bool mono = zlast == (long long)(int)zlast;
+                const int ch0 = bbeg >> 6, ch1 = bend >> 6;
+                int carry = 0;
+                for (int cb = ch0; cb <= ch1; cb += 64) {
+                    const int ch = cb + lane;
+                    bool need = ch <= ch1;
+                    if (need && mono) {
+                        const int xa = max(bbeg, ch << 6), xe = min(bend, (ch << 6) + 63);
+                        const int za = wadd(bS0, wmul(xa - bbeg, bI0)) >> 16, ze = wadd(bS0, wmul(xe - bbeg, bI0)) >> 16;
+                        need = min(za, ze) < zcoarse[ch];
+                    }
+                    unsigned long long nm = __ballot(need);
+                    while (nm) {
+                        const int j = __ffsll((long long)nm) - 1;
+                        nm &= nm - 1ull;
+                        const int xb = (cb + j) << 6, x = xb + lane;
+                        const bool in = x >= bbeg && x <= bend;
+                        const int zi = wadd(bS0, wmul(x - bbeg, bI0)) >> 16;
+                        const int zold = x < W ? zrow[x] : INT_MIN;
+                        const bool ps = in && zold > zi;
+                        const unsigned long long pm = __ballot(ps);
+                        if (pm == 0ull) continue;
+                        if (ps) zrow[x] = zi;
+                        int m = ps ? zi : zold;
 #pragma unroll
-                    for (int q = 0; q < NA; q++) { bS[q] = __shfl(S[q], src); bI[q] = __shfl(I[q], src); }
-                    int carry = 0;
-                    for (int xb = bbeg; xb <= bend; xb += 64) {
-                        const int x = xb + lane;
-                        const bool in = x <= bend;
-                        const int kx = x - bbeg;
-                        const int zi = wadd(bS[0], wmul(kx, bI[0])) >> 16;
-                        const bool pass = in && zrow[x < W ? x : W - 1] > zi;
-                        const unsigned long long pm = __ballot(pass);
-                        if (pass) {
-                            const int nb = carry + __popcll(pm & ((1ull << lane) - 1ull));
-                            int c = bh.z;
-                            if (NA > 1 && bkind != KIND_FLAT)
-                                c = pixel_colour<NA>(a, bh, bpoly, x, y, bbeg, bend, bS, bI, bkind >= KIND_TEX_LIN ? nb : kx);
-                            zrow[x] = zi;
-                            crow[x] = c;
+                        for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
+                        if (lane == 0) zcoarse[cb + j] = m;
+                        if (!immediate && nent == 64) go_immediate();
+                        if (!immediate) {
+                            if (lane == nent) {
+                                ent_xb = xb; ent_tag = src | (seq << 8); ent_carry = carry;
+                                ent_lo = (unsigned)pm; ent_hi = (unsigned)(pm >> 32);
+                            }
+                            nent++;
+                        } else if (ps) {
+                            crow[x] = span_colour(sp, x, carry + __popcll(pm & lt_mask));
                         }
                         carry += __popcll(pm);
                     }
-                    LDS_WAVE_SYNC();
+                }
+                if (!immediate) { long_seqs |= 1ull << seq; seq++; }
+                LDS_WAVE_SYNC();
+            }
+        }
+        pass_turn(&turn[0], k, lane);
+        if (!immediate) {
+            // ---- colours: nothing shared is touched, the groups behind go on meanwhile
+            colours(pass);
+#pragma unroll
+            for (int q = 0; q < LONG_PRE; q++) {
+                lcol[q] = 0;
+                if (q < nent) {
+                    const unsigned long long pm = (unsigned long long)(unsigned)RL((int)ent_lo, q) |
+                                                  ((unsigned long long)(unsigned)RL((int)ent_hi, q) << 32);
+                    const Span sp = span_of(RL(ent_tag, q) & 0xff);
+                    const int xb = RL(ent_xb, q), cr = RL(ent_carry, q);
+                    if ((pm >> lane) & 1ull) lcol[q] = span_colour(sp, xb + lane, cr + __popcll(pm & lt_mask));
                 }
             }
-            pass_turn(&turn[0], k, lane);
-            pass_turn(&turn[1], k, lane);
+            // ---- colour writes in draw order: groups by turn, inside a group by sequence number
+            wait_turn(&turn[1], k);
+            flush(true);
         }
+        pass_turn(&turn[1], k, lane);
     }
     __syncthreads();
     for (int p = t; p < W; p += 64 * NW) {
@@ -2495,7 +2597,7 @@ void ordered_list_layout(int W, int H, int *R, int *cshift, size_t *lds)
     if (r > 16) r = 16;
     if (r > H) r = H;
     *R = r;
-    *lds = (size_t)W * 8 + ((size_t)(W >> *cshift) + 1 + 2) * sizeof(unsigned);
+    *lds = (size_t)W * 8 + ((size_t)(W >> *cshift) + 1 + 2 + (size_t)((W + 63) >> 6)) * sizeof(unsigned);
 }
 
 bool band_lists_possible(int W, int H, int *R, int *nb)

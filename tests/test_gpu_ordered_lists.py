@@ -85,6 +85,21 @@ def test_dense_overlap_many_rounds(env):
     assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
 
 
+@pytest.mark.parametrize("radius,lin_percent", [(150, 100), (60, 70), (400, 100)])
+def test_groups_of_long_spans(env, radius, lin_percent):
+    """wide triangles only: every group of 64 list entries is all long spans, more chunks with
+    passes and more sequence numbers than a group records, so the rest of a group is drawn with
+    both turns held"""
+    P, G = env
+    sc = S.gen_c3(2500, 640, 480, 9, radius=radius, equal_lights=False, lin_percent=lin_percent, seed=0xC0FFEE90 + radius,
+                  regular_mapping=True)
+    orc = _oracle(P, [sc], 640, 480)
+    ctx = _gpu(P, G, [sc], 640, 480, LISTS_ALWAYS)
+    c, z = ctx.readback(check=False)
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert ctx.counters()["fragments"] == orc.counters()["fragments"]
+
+
 def test_several_batches_in_one_frame_and_frames_in_flight(env):
     """three textured batches drawn over each other, twice without a flush (two frames in
     flight, work sets in turns): every batch has its own lists"""
