@@ -1440,6 +1440,61 @@ __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, 
     return true;
 }
 
+// The same row in two steps, for the draw-order fill: first which edges hold the row's two ends,
+// with the depth there (everything the depth tests need, from the depth pieces of the edges:
+// `p0` holds those of edges 0..2), then -- only for rows that get a colour -- the other
+// interpolated values at the two ends.
+struct RowOwners { int beg, end, be, bi, ee, ei; };
+
+template <int NA>
+__device__ __forceinline__ bool row_owners(const int *__restrict__ edges, int np, int poly, int ne, int y, const int4 (&p0)[3],
+                                           RowOwners &o, int &zs, int &ze)
+{
+    constexpr int ESZ = edge_ints(NA);
+    int bx = INT_MAX, ex = INT_MIN, be = 0, bi = 0, ee = 0, ei = 0;
+    int bz0 = 0, bzi = 0, ez0 = 0, ezi = 0;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        int ia, xa, ib, xb;
+        if (e < ne && edge_row(p0[e].x, p0[e].y, y, ia, xa, ib, xb)) {
+            if (xa < bx) { bx = xa; be = e; bi = ia; bz0 = p0[e].z; bzi = p0[e].w; }
+            if (ex < xb) { ex = xb; ee = e; ei = ib; ez0 = p0[e].z; ezi = p0[e].w; }
+        }
+    }
+    for (int e = 3; e < ne; e++) {
+        const int4 r = *edge_piece(edges, np, ESZ / 4, e, 0, poly);
+        int ia, xa, ib, xb;
+        if (!edge_row(r.x, r.y, y, ia, xa, ib, xb)) continue;
+        if (xa < bx) { bx = xa; be = e; bi = ia; bz0 = r.z; bzi = r.w; }
+        if (ex < xb) { ex = xb; ee = e; ei = ib; ez0 = r.z; ezi = r.w; }
+    }
+    if (bx == INT_MAX) return false;
+    zs = wadd(bz0, wmul(bi, bzi));
+    ze = wadd(ez0, wmul(ei, ezi));
+    o.beg = bx; o.end = ex; o.be = be; o.bi = bi; o.ee = ee; o.ei = ei;
+    return true;
+}
+
+// S[1..NA-1], E[1..NA-1] of row_ends() for the owners found by row_owners()
+template <int NA>
+__device__ __forceinline__ void row_attrs(const int *__restrict__ edges, int np, int poly, const RowOwners &o, int (&S)[NA],
+                                          int (&E)[NA])
+{
+    constexpr int ESZ = edge_ints(NA);
+    int rb[ESZ], re[ESZ];
+#pragma unroll
+    for (int q = 1; q < ESZ / 4; q++) {
+        const int4 vb = *edge_piece(edges, np, ESZ / 4, o.be, q, poly), ve = *edge_piece(edges, np, ESZ / 4, o.ee, q, poly);
+        rb[4 * q] = vb.x; rb[4 * q + 1] = vb.y; rb[4 * q + 2] = vb.z; rb[4 * q + 3] = vb.w;
+        re[4 * q] = ve.x; re[4 * q + 1] = ve.y; re[4 * q + 2] = ve.z; re[4 * q + 3] = ve.w;
+    }
+#pragma unroll
+    for (int q = 1; q < NA; q++) {
+        S[q] = wadd(rb[3 + q], wmul(o.bi, rb[3 + (NA - 1) + q]));
+        E[q] = wadd(re[3 + q], wmul(o.ei, re[3 + (NA - 1) + q]));
+    }
+}
+
 // (depth, draw index) packed for a signed 64-bit minimum: the depth is the signed high
 // word, and between equal depths the low word compares as an unsigned magnitude.
 __device__ __forceinline__ long long depth_key(int z, unsigned id)
@@ -1801,8 +1856,10 @@ __global__ void __launch_bounds__(1024) band_scan_kernel(BandArgs a, int nchunks
 //  - a group with a longer span in it waits until every earlier group has finished and is
 //    drawn polygon after polygon, 64 pixels of a span per step (ballot and prefix count of
 //    the passes), as in the kernel above.
+__device__ int g_dbg_nowait;
 __device__ __forceinline__ void wait_turn(const unsigned *word, unsigned k)
 {
+    if (g_dbg_nowait) return;
     while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(2);
 }
 __device__ __forceinline__ void pass_turn(unsigned *word, unsigned k, int lane)
@@ -1812,13 +1869,14 @@ __device__ __forceinline__ void pass_turn(unsigned *word, unsigned k, int lane)
 }
 
 template <int NA, int NW>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) ordered_list_kernel(RasterArgs a, BandArgs ba, int cshift)
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) ordered_list_kernel(RasterArgs a, BandArgs ba, int cshift, int dbg)
 {
     constexpr int ESZ = edge_ints(NA);
     constexpr int SHORT = 16;                 // spans of up to SHORT pixels are drawn one per lane
     constexpr int LONG_PRE = 4;               // chunks of long spans whose colours are worked out before the colour turn
     extern __shared__ int row_lds[];
     if (!(a.force_order || *a.order_flag == a.order_gen)) return;
+    g_dbg_nowait = dbg & 1;
     const int W = a.W, R = ba.R;
     const int ncell = (W >> cshift) + 1;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1857,61 +1915,120 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
     unsigned long long frags = 0;
     const int4 zero4 = make_int4(0, 0, 0, 0);
     // the list entry, header and edge coordinates of a wave's next group are fetched while it works on this one
-    auto fetch = [&](unsigned k, int &poly, int4 &h, int2 (&xy)[3]) {
+    auto fetch = [&](unsigned k, int &poly, int4 &h, int4 (&p0)[3]) __attribute__((always_inline)) {
         const unsigned ei = k * 64u + (unsigned)lane;
         poly = (k < ngroups && ei < ln) ? (int)ba.list[lb + ei] : -1;
-        if ((unsigned)poly >= (unsigned)a.np) poly = -1;
+        if ((unsigned)poly >= (unsigned)a.np || (dbg & 128)) poly = -1;
         h = zero4;
 #pragma unroll
-        for (int e = 0; e < 3; e++) xy[e] = make_int2(0, 0);
+        for (int e = 0; e < 3; e++) p0[e] = zero4;
         if (poly >= 0) {
+            // header and the depth pieces of edges 0..2: one 64-byte run of the polygon record
             h = *record_header(a.edges, ESZ / 4, poly);
 #pragma unroll
-            for (int e = 0; e < 3; e++) xy[e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
+            for (int e = 0; e < 3; e++) p0[e] = *edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
         }
     };
     int poly_n;
     int4 h_n;
-    int2 xy_n[3];
-    fetch((unsigned)wv, poly_n, h_n, xy_n);
+    int4 p0_n[3];
+    fetch((unsigned)wv, poly_n, h_n, p0_n);
     for (unsigned k = (unsigned)wv; k < ngroups; k += NW) {
-        // ---- the spans of this group's polygons on the row
+        // ---- the spans of this group's polygons on the row: ends and depth only.  The other
+        // interpolated values are fetched after the depth tests, for the spans that get a colour.
         const int poly = poly_n;
         const int4 h = h_n;
-        const int2 xy[3] = {xy_n[0], xy_n[1], xy_n[2]};
-        fetch(k + NW, poly_n, h_n, xy_n);
+        const int4 p0[3] = {p0_n[0], p0_n[1], p0_n[2]};
+        fetch(k + NW, poly_n, h_n, p0_n);
         const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff;
         int S[NA], E[NA], I[NA], beg = 0, end = -1;
-        bool hit = poly >= 0 && ne != 0 && y >= (h.x & 0xffff) && y < ((h.x >> 16) & 0xffff);
-        if (hit) hit = row_ends<NA>(a.edges, a.np, poly, ne, y, beg, end, S, E, xy);
 #pragma unroll
-        for (int q = 0; q < NA; q++) I[q] = 0;
+        for (int q = 0; q < NA; q++) { S[q] = 0; E[q] = 0; I[q] = 0; }
+        RowOwners ow{};
+        bool hit = poly >= 0 && ne != 0 && y >= (h.x & 0xffff) && y < ((h.x >> 16) & 0xffff);
+        if (dbg & 64) hit = false;
+        if (hit) hit = row_owners<NA>(a.edges, a.np, poly, ne, y, p0, ow, S[0], E[0]);
         if (hit) {
+            beg = ow.beg; end = ow.end;
             int span = end - beg;
             if (span == 0) span = 1;
-            const double rs = drcp(span);
-#pragma unroll
-            for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+            I[0] = tdivr(wsub(E[0], S[0]), drcp(span));
             frags += (unsigned long long)(end - beg + 1);
         }
+        int4 hc = h;
+        int ckind = kind;
+        bool have_attr = false;
+        // the values a span's colours need: light and texture coordinates at its ends, increments.
         // A span of up to 32 pixels is one linear run of the perspective mapper (GraphicsPoly.cpp:626):
         // its texture coordinates are start + pixel * increment, the linear mapper's form, so
         // the run is worked out once here and the colours below know only that form.
-        int4 hc = h;
-        if (NA == 6 && hit && kind == KIND_TEX_PRP && end - beg < SHORT) {
-            prp_run(a, poly, y, beg - W / 2, end - W / 2, end - beg, S[4 % NA], S[5 % NA], I[4 % NA], I[5 % NA]);
-            hc.w = (h.w & ~0xff00) | (KIND_TEX_LIN << 8);
+        auto attrs = [&](bool want) __attribute__((always_inline)) {
+            want = want && hit && !have_attr;
+            if (want) {
+                row_attrs<NA>(a.edges, a.np, poly, ow, S, E);
+                int span = end - beg;
+                if (span == 0) span = 1;
+                const double rs = drcp(span);
+#pragma unroll
+                for (int q = 1; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+                have_attr = true;
+            }
+            if (NA == 6 && want && kind == KIND_TEX_PRP && end - beg < SHORT && !(dbg & 32)) {
+                prp_run(a, poly, y, beg - W / 2, end - W / 2, end - beg, S[4 % NA], S[5 % NA], I[4 % NA], I[5 % NA]);
+                hc.w = (h.w & ~0xff00) | (KIND_TEX_LIN << 8);
+                ckind = KIND_TEX_LIN;
+            }
+        };
+        // ---- before the turn: depth values only get smaller, so a span none of whose pixels
+        // passes against what the row holds now (earlier groups may still be lowering it) cannot
+        // pass in its turn either, and a span without a pass changes nothing: it drops out here.
+        // The others fetch what their colours need while they wait for the turn.
+        if (hit && end - beg < SHORT) {
+            const int n = end - beg;
+            int z = S[0];
+            bool may = false;
+#pragma unroll
+            for (int b4 = 0; b4 < SHORT / 4; b4++) {
+                if (n >= 4 * b4) {
+                    int zo[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) zo[q] = zrow[beg + min(4 * b4 + q, n)];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) may = may || zo[q] > (wadd(z, wmul(q, I[0])) >> 16);
+                }
+                z = wadd(z, wshl(I[0], 2));
+            }
+            hit = may;
         }
-        const int ckind = (hc.w >> 8) & 0xff;
+        for (unsigned long long lm = __ballot(hit && end - beg >= SHORT); lm; lm &= lm - 1ull) {
+            const int src = __ffsll((long long)lm) - 1;
+            const int bbeg = __builtin_amdgcn_readlane(beg, src), bend = __builtin_amdgcn_readlane(end, src);
+            const int bS0 = __builtin_amdgcn_readlane(S[0], src), bI0 = __builtin_amdgcn_readlane(I[0], src);
+            const long long zlast = (long long)bS0 + (long long)(bend - bbeg) * bI0;
+            bool any = zlast != (long long)(int)zlast;          // a wrap along the span: no coarse test
+            const int ch0 = bbeg >> 6, ch1 = bend >> 6;
+            for (int cb = ch0; cb <= ch1 && !any; cb += 64) {
+                const int ch = cb + lane;
+                bool need = false;
+                if (ch <= ch1) {
+                    const int xa = max(bbeg, ch << 6), xe = min(bend, (ch << 6) + 63);
+                    const int za = wadd(bS0, wmul(xa - bbeg, bI0)) >> 16, ze = wadd(bS0, wmul(xe - bbeg, bI0)) >> 16;
+                    need = min(za, ze) < zcoarse[ch];
+                }
+                any = __ballot(need) != 0ull;
+            }
+            if (!any && lane == src) hit = false;
+        }
         const unsigned long long hits = __ballot(hit);
         const unsigned long long longs = __ballot(hit && end - beg >= SHORT);
+        attrs(true);
 
         const int c0 = beg >> cshift, c1 = end >> cshift;          // a short span touches at most three cells
         // One round of the short spans in `rem`: lanes claim their cells; those that hold them all
         // test their pixels against the row's depth values (GraphicsPoly.cpp:469-472; the values
         // are read together, one LDS round trip, then compared and lowered) and free the cells.
         // Returns the lanes that went; `pass` gets a bit per pixel that passed.
-        auto depth_round = [&](unsigned long long rem, unsigned &pass) -> unsigned long long {
+        auto depth_round = [&](unsigned long long rem, unsigned &pass) __attribute__((always_inline)) -> unsigned long long {
             const bool mine = (rem >> lane) & 1ull;
             if (mine) {
                 atomicMin(&cells[c0], (unsigned)lane);
@@ -1925,16 +2042,22 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
                      (c1 <= c0 + 1 || cells[c1] == (unsigned)lane);
             LDS_WAVE_SYNC();
             if (go) {
+                // four pixels at a time; only the lanes whose span reaches a block touch the row
                 const int n = end - beg;
-                int zo[SHORT];
-#pragma unroll
-                for (int q = 0; q < SHORT; q++) zo[q] = zrow[beg + (q <= n ? q : n)];
                 int z = S[0];
 #pragma unroll
-                for (int q = 0; q < SHORT; q++) {
-                    const int zi = z >> 16;
-                    if (q <= n && zo[q] > zi) { zrow[beg + q] = zi; pass |= 1u << q; }
-                    z = wadd(z, I[0]);
+                for (int b4 = 0; b4 < SHORT / 4; b4++) {
+                    if (n >= 4 * b4) {
+                        int zo[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) zo[q] = zrow[beg + min(4 * b4 + q, n)];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int zi = wadd(z, wmul(q, I[0])) >> 16;
+                            if (4 * b4 + q <= n && zo[q] > zi) { zrow[beg + 4 * b4 + q] = zi; pass |= 1u << (4 * b4 + q); }
+                        }
+                    }
+                    z = wadd(z, wshl(I[0], 2));
                 }
                 cells[c0] = ~0u;
                 if (c1 > c0) cells[c0 + 1] = ~0u;
@@ -1947,7 +2070,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
         // (textured fills, GraphicsPoly.cpp:485-493), once per pixel (shaded).  Four pixels at a
         // time, so that their texel loads are in flight together.
         int col[SHORT];
-        auto colours = [&](unsigned pass) {
+        auto colours = [&](unsigned pass) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < SHORT; q++) col[q] = hc.z;
 #pragma unroll
@@ -1975,7 +2098,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
                 }
             }
         };
-        auto write_colours = [&](unsigned pass) {
+        auto write_colours = [&](unsigned pass) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < SHORT; q++)
                 if ((pass >> q) & 1u) crow[beg + q] = col[q];
@@ -1992,13 +2115,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
         int nent = 0, seq = 0, my_seq = -1;
         unsigned pass = 0u;
         unsigned long long long_seqs = 0ull;          // bit s: sequence number s is a long span
+        unsigned long long long_used = 0ull;          // lanes whose long span has a recorded chunk
         bool immediate = false;                       // colours written at once, both turns held
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        auto RL = [&](int v, int l) { return __builtin_amdgcn_readlane(v, l); };
+        auto RL = [&](int v, int l) __attribute__((always_inline)) { return __builtin_amdgcn_readlane(v, l); };
         // a long span's data, read from the lane that holds it (wave-uniform values), and the
         // colour of its pixel x after `nbk` earlier passes
         struct Span { int4 h; int poly, beg, end; int S[NA], I[NA]; };
-        auto span_of = [&](int src) -> Span {
+        auto span_of = [&](int src) __attribute__((always_inline)) -> Span {
             Span sp;
             sp.h = make_int4(RL(h.x, src), RL(h.y, src), RL(h.z, src), RL(h.w, src));
             sp.poly = RL(poly, src); sp.beg = RL(beg, src); sp.end = RL(end, src);
@@ -2006,14 +2130,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
             for (int q = 0; q < NA; q++) { sp.S[q] = RL(S[q], src); sp.I[q] = RL(I[q], src); }
             return sp;
         };
-        auto span_colour = [&](const Span &sp, int x, int nbk) -> int {
+        auto span_colour = [&](const Span &sp, int x, int nbk) __attribute__((always_inline)) -> int {
             const int bkind = (sp.h.w >> 8) & 0xff;
             if (NA == 1 || bkind == KIND_FLAT) return sp.h.z;
             return pixel_colour<NA>(a, sp.h, sp.poly, x, y, sp.beg, sp.end, sp.S, sp.I, bkind >= KIND_TEX_LIN ? nbk : x - sp.beg);
         };
         int lcol[LONG_PRE];
         // colour writes of everything recorded so far, in sequence order (under the colour turn)
-        auto flush = [&](bool pre) {
+        auto flush = [&](bool pre) __attribute__((always_inline)) {
             int e = 0;
             for (int sq = 0; sq < seq; sq++) {
                 if ((long_seqs >> sq) & 1ull) {
@@ -2042,8 +2166,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
         };
         // more long spans or rounds than the records hold: take the colour turn as well, write what
         // is pending, and draw the rest of the group with its colours at once
-        auto go_immediate = [&]() {
+        auto go_immediate = [&]() __attribute__((always_inline)) {
             wait_turn(&turn[1], k);
+            attrs(true);
             colours(pass);
             flush(false);
             immediate = true;
@@ -2059,7 +2184,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
             for (unsigned long long rem = sub; rem;) {
                 if (!immediate && seq >= 63) go_immediate();
                 unsigned long long went;
-                if (!immediate) {
+                if (dbg & 4) { went = rem; seq++; } else if (!immediate) {
                     went = depth_round(rem, pass);
                     if ((went >> lane) & 1ull) my_seq = seq;
                     seq++;
@@ -2077,7 +2202,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
                 const int src = first_long;
                 todo &= ~(1ull << src);
                 if (!immediate && seq >= 63) go_immediate();
-                const Span sp = span_of(src);
+                Span sp = span_of(src);
                 const int bbeg = sp.beg, bend = sp.end, bS0 = sp.S[0], bI0 = sp.I[0];
                 // without a 32-bit wrap along the span the depth runs monotonically: a chunk's
                 // smallest depth is at one of its ends
@@ -2085,7 +2210,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
                 const bool mono = zlast == (long long)(int)zlast;
                 const int ch0 = bbeg >> 6, ch1 = bend >> 6;
                 int carry = 0;
-                for (int cb = ch0; cb <= ch1; cb += 64) {
+                for (int cb = ch0; cb <= ch1 && !(dbg & 2); cb += 64) {
                     const int ch = cb + lane;
                     bool need = ch <= ch1;
                     if (need && mono) {
@@ -2109,8 +2234,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
                         for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
                         if (lane == 0) zcoarse[cb + j] = m;
-                        if (!immediate && nent == 64) go_immediate();
+                        if (!immediate && nent == 64) { go_immediate(); sp = span_of(src); }
                         if (!immediate) {
+                            long_used |= 1ull << src;
                             if (lane == nent) {
                                 ent_xb = xb; ent_tag = src | (seq << 8); ent_carry = carry;
                                 ent_lo = (unsigned)pm; ent_hi = (unsigned)(pm >> 32);
@@ -2129,11 +2255,12 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
         pass_turn(&turn[0], k, lane);
         if (!immediate) {
             // ---- colours: nothing shared is touched, the groups behind go on meanwhile
-            colours(pass);
+            attrs(pass != 0u || ((long_used >> lane) & 1ull));
+            if (!(dbg & 8)) colours(pass);
 #pragma unroll
             for (int q = 0; q < LONG_PRE; q++) {
                 lcol[q] = 0;
-                if (q < nent) {
+                if (q < nent && !(dbg & 8)) {
                     const unsigned long long pm = (unsigned long long)(unsigned)RL((int)ent_lo, q) |
                                                   ((unsigned long long)(unsigned)RL((int)ent_hi, q) << 32);
                     const Span sp = span_of(RL(ent_tag, q) & 0xff);
@@ -2143,7 +2270,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4,
             }
             // ---- colour writes in draw order: groups by turn, inside a group by sequence number
             wait_turn(&turn[1], k);
-            flush(true);
+            if (!(dbg & 16)) flush(true);
         }
         pass_turn(&turn[1], k, lane);
     }
@@ -2650,7 +2777,7 @@ hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const 
     hipLaunchKernelGGL((band_bin_kernel<false>), dim3(bin_grid), dim3(256), bits, s, *bands, nchunks);
     hipLaunchKernelGGL(band_scan_kernel, dim3((bands->nb + 63) / 64), dim3(1024), 0, s, *bands, nchunks);
     hipLaunchKernelGGL((band_bin_kernel<true>), dim3(bin_grid), dim3(256), bits, s, *bands, nchunks);
-    hipLaunchKernelGGL((ordered_list_kernel<6, ORDERED_WAVES>), dim3(((bands->nb + 7) / 8) * 8 * R), dim3(64 * ORDERED_WAVES), lds, s, a, *bands, cshift);
+    hipLaunchKernelGGL((ordered_list_kernel<6, ORDERED_WAVES>), dim3(((bands->nb + 7) / 8) * 8 * R), dim3(64 * ORDERED_WAVES), lds, s, a, *bands, cshift, getenv("LT_DBG") ? atoi(getenv("LT_DBG")) : 0);
     return hipSuccess;
 }
 
