@@ -407,6 +407,9 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
         if ((rc = new_event(c, (hipStream_t)-1, &scan_idx))) return rc;
         scan_ev = c->ev_pool[scan_idx];
     }
+    const bool ordered_follows = dim == 8 && c->order_mode != LT_ORDER_NEVER;
+    const bool band_lists = ordered_follows && wa.blist;
+    const int order_force = (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0;
     launch_binning(gs, wa.hdr, np, twl, tiles_x, ntiles, wa.tcount, wa.toffset, wa.tcursor, wa.list, capacity,
                    screen ? nullptr : sa.queue_count, c->status, scan_ev, fused, geom_done);
     if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
@@ -414,6 +417,16 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
         lt_ctx::Span sp{3, scan_idx, 0};
         c->spans.push_back(sp);
         if ((rc = stage_end(c, 3, gs))) return rc;
+    }
+    BandArgs ba{};
+    if (band_lists) {
+        ba.hdr = wa.hdr; ba.np = np;
+        ba.R = pl.band_rows; ba.nb = pl.nbands;
+        ba.cnt = wa.bcnt; ba.base = wa.bplace; ba.total = wa.bplace + pl.nbands;
+        ba.list = wa.blist; ba.capacity = pl.band_capacity;
+        ba.alloc = (unsigned *)(order_flag + 1);
+        ba.order_flag = order_flag; ba.order_gen = order_gen; ba.force_order = order_force;
+        ba.status = c->status;
     }
     if (geom_done) HIPCHK(c, hipStreamWaitEvent(rs, geom_done, 0));      // the scatter's completion
 
@@ -428,26 +441,18 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
     ra.prp = want_prp ? wa.prp : nullptr; ra.log_focus = log_focus;
     ra.tex_ptr = (const int *const *)c->tex_ptr_d; ra.tex_log = c->tex_log_d;
     ra.order_flag = order_flag; ra.order_gen = order_gen;
-    ra.force_order = (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0;
+    ra.force_order = order_force;
     ra.band_y0 = c->band_y0; ra.band_y1 = c->band_y1;
     ra.status = c->status;
     // The fill's events are its own dispatch's where no other kernel follows it: its start
     // and end for the stage timing, else its completion as this work set's "free" signal.
-    const bool ordered_follows = dim == 8 && c->order_mode != LT_ORDER_NEVER;
     if (ordered_follows) {
         if ((rc = stage_begin(c, 4, rs))) return rc;
         launch_raster(rs, na, tile_w, ra, nullptr, nullptr);
-        BandArgs ba{};
-        if (wa.blist) {
-            ba.hdr = wa.hdr; ba.np = np;
-            ba.R = pl.band_rows; ba.nb = pl.nbands;
-            ba.cnt = wa.bcnt; ba.base = wa.bplace; ba.total = wa.bplace + pl.nbands;
-            ba.list = wa.blist; ba.capacity = pl.band_capacity;
-            ba.alloc = (unsigned *)(order_flag + 1);
-            ba.order_flag = order_flag; ba.order_gen = order_gen; ba.force_order = ra.force_order;
-            ba.status = c->status;
-        }
-        HIPCHK(c, launch_ordered(rs, ra, c->device, wa.blist ? &ba : nullptr));
+        // (the per-band lists on the fill's stream: made on the geometry stream, beside the fill of
+        // the batch before, they slow that fill down by more than they take here)
+        if (band_lists) HIPCHK(c, launch_band_lists(rs, np, c->device, ba));
+        HIPCHK(c, launch_ordered(rs, ra, c->device, band_lists ? &ba : nullptr));
         if ((rc = stage_end(c, 4, rs))) return rc;
         if (raster_done) HIPCHK(c, hipEventRecord(raster_done, rs));
     } else if (timed(c, 4)) {

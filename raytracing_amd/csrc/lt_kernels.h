@@ -138,6 +138,7 @@ struct BandArgs {
     Status *status;
 };
 bool band_lists_possible(int W, int H, int *R, int *nb);
+hipError_t launch_band_lists(hipStream_t s, int np, int device, const BandArgs &bands);
 
 // Shading pre-pass (M_shade_polygon_object, EngPoly.cpp:464-493).
 constexpr int MAX_LIGHTS = 16;

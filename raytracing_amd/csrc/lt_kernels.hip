@@ -1841,25 +1841,31 @@ __global__ void __launch_bounds__(1024) band_scan_kernel(BandArgs a, int nchunks
 // The draw-order fill of one row from its band's list: one workgroup per row (depth and colour
 // of the row in LDS), its NW waves taking groups of 64 list entries in turn (group g goes to
 // wave g mod NW).  For a group:
-//  - all 64 lanes evaluate their polygon's span on the row (ends, start values, increments);
-//    this does not depend on what is in the row, so the waves do it side by side;
+//  - all 64 lanes find their polygon's span on the row: its two ends and the depth there, from
+//    the 64-byte run of the polygon record that was fetched a group ahead.  This does not
+//    depend on what is in the row, so the waves do it side by side;
+//  - still outside any turn, every span is tested against the depth values the row holds at
+//    that moment (a long span against a coarse table: the largest depth of each aligned
+//    64-pixel chunk).  Depth values only get smaller, so a span that passes nowhere now passes
+//    nowhere in its turn, and such a span changes nothing: it drops out.  The others fetch what
+//    their colours need (light and texture coordinates at the row's ends) while they wait;
 //  - then the group waits for its turn at the row's depth values (LDS word turn[0]).  Spans
-//    of up to 16 pixels -- batches of many small polygons -- are depth-tested one per lane,
-//    pixel by pixel, in rounds: a lane may go once no earlier polygon of the 64 that is still
-//    waiting has a span near its own.  Lanes claim the 8- or 16-pixel cells that their span
-//    touches with their lane number (an LDS minimum); a lane that holds all of its cells has
-//    no earlier neighbour left, tests its pixels, keeps a bit mask of the passes and frees its
-//    cells.  The lowest waiting lane always holds its cells: every round makes progress;
+//    of up to 16 pixels are depth-tested one per lane in rounds: a lane may go once no earlier
+//    polygon of the 64 that is still waiting has a span near its own.  Lanes claim the 8- or
+//    16-pixel cells that their span touches with their lane number (an LDS minimum); a lane
+//    that holds all of its cells has no earlier neighbour left, tests its pixels, keeps a bit
+//    mask of the passes and frees its cells.  The lowest waiting lane always holds its cells:
+//    every round makes progress.  A longer span is swept between the rounds of the short spans
+//    before it and after it, chunk by chunk (chunks the coarse table rejects are skipped), a
+//    pixel per lane; the pass mask of a chunk with passes is recorded;
 //  - with the depth values updated the next group may start on them; this one computes the
 //    colours of its passes (texel loads, light from the pass count: GraphicsPoly.cpp:485-493)
-//    and writes them when its turn at the row's colours has come (turn[1]), round by round;
-//  - a group with a longer span in it waits until every earlier group has finished and is
-//    drawn polygon after polygon, 64 pixels of a span per step (ballot and prefix count of
-//    the passes), as in the kernel above.
-__device__ int g_dbg_nowait;
+//    and writes them when its turn at the row's colours has come (turn[1]), in the order the
+//    depth tests were made;
+//  - a group with more long-span chunks or rounds than it can record takes the colour turn
+//    early, writes what is pending and draws the rest with both turns held.
 __device__ __forceinline__ void wait_turn(const unsigned *word, unsigned k)
 {
-    if (g_dbg_nowait) return;
     while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != k) __builtin_amdgcn_s_sleep(2);
 }
 __device__ __forceinline__ void pass_turn(unsigned *word, unsigned k, int lane)
@@ -1869,14 +1875,13 @@ __device__ __forceinline__ void pass_turn(unsigned *word, unsigned k, int lane)
 }
 
 template <int NA, int NW>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) ordered_list_kernel(RasterArgs a, BandArgs ba, int cshift, int dbg)
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3, 3))) ordered_list_kernel(RasterArgs a, BandArgs ba, int cshift)
 {
     constexpr int ESZ = edge_ints(NA);
     constexpr int SHORT = 16;                 // spans of up to SHORT pixels are drawn one per lane
     constexpr int LONG_PRE = 4;               // chunks of long spans whose colours are worked out before the colour turn
     extern __shared__ int row_lds[];
     if (!(a.force_order || *a.order_flag == a.order_gen)) return;
-    g_dbg_nowait = dbg & 1;
     const int W = a.W, R = ba.R;
     const int ncell = (W >> cshift) + 1;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1918,7 +1923,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
     auto fetch = [&](unsigned k, int &poly, int4 &h, int4 (&p0)[3]) __attribute__((always_inline)) {
         const unsigned ei = k * 64u + (unsigned)lane;
         poly = (k < ngroups && ei < ln) ? (int)ba.list[lb + ei] : -1;
-        if ((unsigned)poly >= (unsigned)a.np || (dbg & 128)) poly = -1;
+        if ((unsigned)poly >= (unsigned)a.np) poly = -1;
         h = zero4;
 #pragma unroll
         for (int e = 0; e < 3; e++) p0[e] = zero4;
@@ -1946,7 +1951,6 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
         for (int q = 0; q < NA; q++) { S[q] = 0; E[q] = 0; I[q] = 0; }
         RowOwners ow{};
         bool hit = poly >= 0 && ne != 0 && y >= (h.x & 0xffff) && y < ((h.x >> 16) & 0xffff);
-        if (dbg & 64) hit = false;
         if (hit) hit = row_owners<NA>(a.edges, a.np, poly, ne, y, p0, ow, S[0], E[0]);
         if (hit) {
             beg = ow.beg; end = ow.end;
@@ -1973,7 +1977,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
                 for (int q = 1; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
                 have_attr = true;
             }
-            if (NA == 6 && want && kind == KIND_TEX_PRP && end - beg < SHORT && !(dbg & 32)) {
+            if (NA == 6 && want && kind == KIND_TEX_PRP && end - beg < SHORT) {
                 prp_run(a, poly, y, beg - W / 2, end - W / 2, end - beg, S[4 % NA], S[5 % NA], I[4 % NA], I[5 % NA]);
                 hc.w = (h.w & ~0xff00) | (KIND_TEX_LIN << 8);
                 ckind = KIND_TEX_LIN;
@@ -2184,7 +2188,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
             for (unsigned long long rem = sub; rem;) {
                 if (!immediate && seq >= 63) go_immediate();
                 unsigned long long went;
-                if (dbg & 4) { went = rem; seq++; } else if (!immediate) {
+                if (!immediate) {
                     went = depth_round(rem, pass);
                     if ((went >> lane) & 1ull) my_seq = seq;
                     seq++;
@@ -2210,7 +2214,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
                 const bool mono = zlast == (long long)(int)zlast;
                 const int ch0 = bbeg >> 6, ch1 = bend >> 6;
                 int carry = 0;
-                for (int cb = ch0; cb <= ch1 && !(dbg & 2); cb += 64) {
+                for (int cb = ch0; cb <= ch1; cb += 64) {
                     const int ch = cb + lane;
                     bool need = ch <= ch1;
                     if (need && mono) {
@@ -2256,11 +2260,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
         if (!immediate) {
             // ---- colours: nothing shared is touched, the groups behind go on meanwhile
             attrs(pass != 0u || ((long_used >> lane) & 1ull));
-            if (!(dbg & 8)) colours(pass);
+            colours(pass);
 #pragma unroll
             for (int q = 0; q < LONG_PRE; q++) {
                 lcol[q] = 0;
-                if (q < nent && !(dbg & 8)) {
+                if (q < nent) {
                     const unsigned long long pm = (unsigned long long)(unsigned)RL((int)ent_lo, q) |
                                                   ((unsigned long long)(unsigned)RL((int)ent_hi, q) << 32);
                     const Span sp = span_of(RL(ent_tag, q) & 0xff);
@@ -2270,7 +2274,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
             }
             // ---- colour writes in draw order: groups by turn, inside a group by sequence number
             wait_turn(&turn[1], k);
-            if (!(dbg & 16)) flush(true);
+            flush(true);
         }
         pass_turn(&turn[1], k, lane);
     }
@@ -2752,10 +2756,26 @@ static hipError_t allow_large_lds(F fn, std::atomic<bool> (&done)[MAX_DEVICES], 
 constexpr int ORDERED_WAVES = 4;           // waves that share one row of the list-driven draw-order kernel
 constexpr int BAND_BIN_MAX_GRID = 1024;    // workgroups of the band binning (they stride over the chunks)
 
-// `bands` (may be null): work arrays for per-band lists; without them every band reads every header
+// Per-band lists of a batch (needs the batch's headers: after set-up, any stream)
+hipError_t launch_band_lists(hipStream_t s, int np, int device, const BandArgs &bands)
+{
+    static std::atomic<bool> set_count[MAX_DEVICES], set_scatter[MAX_DEVICES];
+    hipError_t e;
+    if ((e = allow_large_lds(band_bin_kernel<false>, set_count, device)) != hipSuccess) return e;
+    if ((e = allow_large_lds(band_bin_kernel<true>, set_scatter, device)) != hipSuccess) return e;
+    const int nchunks = (np + BAND_CHUNK - 1) / BAND_CHUNK;
+    const size_t bits = (size_t)bands.nb * BAND_PITCH * sizeof(unsigned);
+    const int bin_grid = nchunks < BAND_BIN_MAX_GRID ? nchunks : BAND_BIN_MAX_GRID;
+    hipLaunchKernelGGL((band_bin_kernel<false>), dim3(bin_grid), dim3(256), bits, s, bands, nchunks);
+    hipLaunchKernelGGL(band_scan_kernel, dim3((bands.nb + 63) / 64), dim3(1024), 0, s, bands, nchunks);
+    hipLaunchKernelGGL((band_bin_kernel<true>), dim3(bin_grid), dim3(256), bits, s, bands, nchunks);
+    return hipSuccess;
+}
+
+// `bands` (may be null): the per-band lists made by launch_band_lists; without them every band reads every header
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands)
 {
-    static std::atomic<bool> set_walk[MAX_DEVICES], set_list[MAX_DEVICES], set_count[MAX_DEVICES], set_scatter[MAX_DEVICES];
+    static std::atomic<bool> set_walk[MAX_DEVICES], set_list[MAX_DEVICES];
     hipError_t e;
     if (!bands) {
         const int R = ordered_band_rows(a.W, a.H);
@@ -2769,15 +2789,7 @@ hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const 
     ordered_list_layout(a.W, a.H, &R, &cshift, &lds);
     if (R != bands->R) return hipErrorInvalidValue;
     if ((e = allow_large_lds(ordered_list_kernel<6, ORDERED_WAVES>, set_list, device)) != hipSuccess) return e;
-    if ((e = allow_large_lds(band_bin_kernel<false>, set_count, device)) != hipSuccess) return e;
-    if ((e = allow_large_lds(band_bin_kernel<true>, set_scatter, device)) != hipSuccess) return e;
-    const int nchunks = (a.np + BAND_CHUNK - 1) / BAND_CHUNK;
-    const size_t bits = (size_t)bands->nb * BAND_PITCH * sizeof(unsigned);
-    const int bin_grid = nchunks < BAND_BIN_MAX_GRID ? nchunks : BAND_BIN_MAX_GRID;
-    hipLaunchKernelGGL((band_bin_kernel<false>), dim3(bin_grid), dim3(256), bits, s, *bands, nchunks);
-    hipLaunchKernelGGL(band_scan_kernel, dim3((bands->nb + 63) / 64), dim3(1024), 0, s, *bands, nchunks);
-    hipLaunchKernelGGL((band_bin_kernel<true>), dim3(bin_grid), dim3(256), bits, s, *bands, nchunks);
-    hipLaunchKernelGGL((ordered_list_kernel<6, ORDERED_WAVES>), dim3(((bands->nb + 7) / 8) * 8 * R), dim3(64 * ORDERED_WAVES), lds, s, a, *bands, cshift, getenv("LT_DBG") ? atoi(getenv("LT_DBG")) : 0);
+    hipLaunchKernelGGL((ordered_list_kernel<6, ORDERED_WAVES>), dim3(((bands->nb + 7) / 8) * 8 * R), dim3(64 * ORDERED_WAVES), lds, s, a, *bands, cshift);
     return hipSuccess;
 }
 
