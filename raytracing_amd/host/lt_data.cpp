@@ -108,6 +108,10 @@ struct Loader {
         return T_NAME;
     }
 
+    // Names are kept cut to 31 characters and looked up with the whole token, as the reference
+    // does (strncpy into 32 bytes at data.cpp:718,744; strcmp with the token at :357,:739): a name
+    // of up to 31 characters behaves as there.  A longer one is never found again here; in the
+    // reference its 32 stored bytes have no terminator and the compare reads past them.
     int find_var(const std::string &n) const
     {
         for (size_t i = 0; i < vars.size(); i++) if (vars[i].name == n) return (int)i;
