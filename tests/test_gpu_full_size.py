@@ -29,15 +29,17 @@ def _draw(ctx, sc, d, polys=None, aux=None):
                           max_edges=3)
 
 
-@pytest.mark.parametrize("which", ["c2-small-1M-1080p", "c3-10M-4K"])
+@pytest.mark.parametrize("which", ["c2-small-1M-1080p", "c3-10M-4K", "c3q2-10M-4K"])
 def test_split_redraw_and_bands_keep_the_frame(env, which):
     torch, G = env
     if which.startswith("c2"):
         sc = S.gen_c2(1_000_000, 1920, 1080, 10, radius=8)
     else:
         # configuration 3 at its own size: a third of the triangles meet a screen border or the near
-        # plane, a tenth take the perspective mapper
-        sc = S.gen_c3(10_000_000, 3840, 2160, 11, radius=8, equal_lights=True, lin_percent=90, regular_mapping=True)
+        # plane, a tenth take the perspective mapper; with differing vertex lights the batch is
+        # filled in draw order (groups of 64 list entries: other groups in every variant below)
+        sc = S.gen_c3(10_000_000, 3840, 2160, 11, radius=8, equal_lights=not which.startswith("c3q2"), lin_percent=90,
+                      regular_mapping=True)
     d = _dev(torch, sc)
     ctx = G.Context(sc.width, sc.height)
     for h, (tex, lg) in enumerate(sc.textures):
