@@ -1736,11 +1736,12 @@ __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
 // All of them return at once unless the batch is to be filled in draw order.
 
 constexpr int BAND_CHUNK = 1024;
+constexpr int BAND_THREADS = 1024;          // the bit matrix is large (two workgroups a CU): many waves per workgroup
 constexpr int BAND_WORDS = BAND_CHUNK / 32;
 constexpr int BAND_PITCH = BAND_WORDS + 1;       // LDS words between two bands' rows (bank spread)
 
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) band_bin_kernel(BandArgs a, int nchunks)
+__global__ void __launch_bounds__(BAND_THREADS) band_bin_kernel(BandArgs a, int nchunks)
 {
     extern __shared__ unsigned band_bits[];
     if (!(a.force_order || *a.order_flag == a.order_gen)) return;
@@ -1748,11 +1749,11 @@ __global__ void __launch_bounds__(256) band_bin_kernel(BandArgs a, int nchunks)
     // The grid is capped (the bit matrix is large: few workgroups fit a CU) and strides over the
     // chunks, so a batch that is not filled in draw order costs a few hundred empty workgroups.
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        for (int i = t; i < a.nb * BAND_PITCH; i += 256) band_bits[i] = 0u;
+        for (int i = t; i < a.nb * BAND_PITCH; i += BAND_THREADS) band_bits[i] = 0u;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < BAND_CHUNK / 256; k++) {
-            const int idx = k * 256 + t, slot = chunk * BAND_CHUNK + idx;
+        for (int k = 0; k < BAND_CHUNK / BAND_THREADS; k++) {
+            const int idx = k * BAND_THREADS + t, slot = chunk * BAND_CHUNK + idx;
             if (slot < a.np) {
                 const int4 h = ((const int4 *)a.hdr)[slot];
                 if ((h.w & 0xff) != 0) {
@@ -1763,7 +1764,7 @@ __global__ void __launch_bounds__(256) band_bin_kernel(BandArgs a, int nchunks)
             }
         }
         __syncthreads();
-        for (int b = t; b < a.nb; b += 256) {
+        for (int b = t; b < a.nb; b += BAND_THREADS) {
             const unsigned *row = band_bits + b * BAND_PITCH;
             if (!SCATTER) {
                 unsigned c = 0;
@@ -1796,9 +1797,19 @@ __global__ void __launch_bounds__(1024) band_scan_kernel(BandArgs a, int nchunks
     const int b = blockIdx.x * 64 + lane;
     const bool on = b < a.nb;
     const int per = (nchunks + 15) / 16, c0 = w * per, c1 = min(c0 + per, nchunks);
+    // (eight loads in flight: a lane's chain of dependent loads is what this kernel lasts)
     unsigned s = 0;
-    if (on)
-        for (int c = c0; c < c1; c++) s += a.cnt[(size_t)c * a.nb + b];
+    if (on) {
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = a.cnt[(size_t)(c + q) * a.nb + b];
+#pragma unroll
+            for (int q = 0; q < 8; q++) s += v[q];
+        }
+        for (; c < c1; c++) s += a.cnt[(size_t)c * a.nb + b];
+    }
     seg[w][lane] = s;
     __syncthreads();
     unsigned pre = 0, tot = 0;
@@ -1829,7 +1840,18 @@ __global__ void __launch_bounds__(1024) band_scan_kernel(BandArgs a, int nchunks
     __syncthreads();
     if (on) {
         unsigned run = pre;
-        for (int c = c0; c < c1; c++) {
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = a.cnt[(size_t)(c + q) * a.nb + b];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                a.cnt[(size_t)(c + q) * a.nb + b] = run;
+                run += v[q];
+            }
+        }
+        for (; c < c1; c++) {
             const size_t i = (size_t)c * a.nb + b;
             const unsigned v = a.cnt[i];
             a.cnt[i] = run;
@@ -2766,9 +2788,9 @@ hipError_t launch_band_lists(hipStream_t s, int np, int device, const BandArgs &
     const int nchunks = (np + BAND_CHUNK - 1) / BAND_CHUNK;
     const size_t bits = (size_t)bands.nb * BAND_PITCH * sizeof(unsigned);
     const int bin_grid = nchunks < BAND_BIN_MAX_GRID ? nchunks : BAND_BIN_MAX_GRID;
-    hipLaunchKernelGGL((band_bin_kernel<false>), dim3(bin_grid), dim3(256), bits, s, bands, nchunks);
+    hipLaunchKernelGGL((band_bin_kernel<false>), dim3(bin_grid), dim3(BAND_THREADS), bits, s, bands, nchunks);
     hipLaunchKernelGGL(band_scan_kernel, dim3((bands.nb + 63) / 64), dim3(1024), 0, s, bands, nchunks);
-    hipLaunchKernelGGL((band_bin_kernel<true>), dim3(bin_grid), dim3(256), bits, s, bands, nchunks);
+    hipLaunchKernelGGL((band_bin_kernel<true>), dim3(bin_grid), dim3(BAND_THREADS), bits, s, bands, nchunks);
     return hipSuccess;
 }
 
