@@ -553,7 +553,7 @@ int wire_begin(lt_ctx *c, hipStream_t *s)
 {
     *s = c->rs;
     c->drawn_since_clear = true;
-    if (c->alt_rs && c->pipelined) {
+    if (c->alt_cbuf && c->pipelined) {
         // the per-pixel winner words are shared by both frames in flight: lines wait for
         // whatever the other frame's stream still holds
         hipStream_t other = c->rs == c->alt_rs ? c->own_rs : c->alt_rs;
@@ -650,8 +650,9 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     CREATECHK(hipMalloc((void **)&c->status, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipMemset(c->status, 0, sizeof(Status) * STATUS_SLOTS));
     CREATECHK(hipStreamCreateWithFlags(&c->own_gs, hipStreamNonBlocking));
-    CREATECHK(hipStreamCreateWithFlags(&c->own_gs2, hipStreamNonBlocking));
     CREATECHK(hipStreamCreateWithFlags(&c->own_rs, hipStreamNonBlocking));
+    CREATECHK(hipStreamCreateWithFlags(&c->alt_rs, hipStreamNonBlocking));
+    CREATECHK(hipStreamCreateWithFlags(&c->own_gs2, hipStreamNonBlocking));
     c->gs = c->own_gs; c->rs = c->own_rs;
     CREATECHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CREATECHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
@@ -816,7 +817,6 @@ static int next_frame_side(lt_ctx *c)
         const size_t n = (size_t)c->W * c->H;
         HIPCHK(c, hipMalloc((void **)&c->alt_cbuf, n * sizeof(int)));
         HIPCHK(c, hipMalloc((void **)&c->alt_zbuf, n * sizeof(int)));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->alt_rs, hipStreamNonBlocking));
     }
     const bool to_alt = c->cbuf == c->own_cbuf;
     c->on_alt = to_alt;
