@@ -407,6 +407,9 @@ def main():
     ap.add_argument("--workload", default="c2-small")
     ap.add_argument("--tris", type=int, default=0, help="triangles per frame (0: the configuration's own: 1M, 10M for c3*)")
     ap.add_argument("--split", default="frames", choices=["frames", "bands"])
+    ap.add_argument("--route", action="store_true",
+                    help="with --split bands: every rank works out the rows of its share of the polygons, the ranks exchange "
+                         "polygon indices by band, and each sets up only the polygons that can touch its band")
     ap.add_argument("--no-pipelining", action="store_true", help="issue every kernel on one stream")
     ap.add_argument("--host-arrays", action="store_true",
                     help="submit from host memory (the boundary's host-pointer entry point): PCIe-inclusive rate, "
@@ -511,6 +514,7 @@ def main():
         my_frames = list(F.frames_for_rank(1024, rank, world))
         mats = [c4_matrix(f) for f in my_frames]
     frame_no = [0]
+    routed = [0]
 
     def step():
         m = sc.matrix
@@ -521,6 +525,20 @@ def main():
             ctx.clear(0)
             ctx.submit_object(sc.verts, sc.polys, sc.polyverts, sc.render_type, sc.log_focus, polyaux=sc.polyaux,
                               matrix=m, force_linear=sc.force_linear, max_edges=3)
+        elif bands and args.route:
+            # routing is part of the step: rows of this rank's share, lists by band, the exchange
+            lo, hi = B.share(rank, world, sc.n_polys)
+            rows = ctx.polygon_rows_dev(d_verts, d_polys[lo:hi], d_pv, sc.log_focus, matrix=m, max_edges=3)
+            mine = B.exchange_lists(B.lists_by_band(rows, lo, world, sc.height), rank, world).long()
+            routed[0] += int(mine.numel())
+            sel_polys = d_polys[mine].contiguous()
+            sel_aux = d_aux[mine].contiguous() if d_aux is not None else None
+            if y0 < y1:
+                ctx.clear(0)
+                if mine.numel():
+                    ctx.submit_object_dev(d_verts, sel_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=sel_aux,
+                                          matrix=m, force_linear=sc.force_linear, max_edges=3)
+            ctx.flush()                          # the selected arrays are read by the library's own streams: keep them until then
         elif not bands or y0 < y1:
             ctx.clear(0)
             ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux,
@@ -630,7 +648,8 @@ def main():
             "data": "synthetic" + (", submitted from host memory every frame (PCIe-inclusive)" if args.host_arrays else ""),
             "config": {"workload": f"{args.workload}: {sc.n_polys} {what} triangles per frame at {sc.width}x{sc.height}, one frame per "
                                    f"step per GPU" + (", per-frame object matrix (frames rank, rank + world, ... of 1024)" if animated else ""),
-                       "parallelism": (f"sort-first row bands x{world}, bands gathered to rank 0" if bands
+                       "parallelism": (f"sort-first row bands x{world}, bands gathered to rank 0"
+                                       + (", polygons routed to their bands before set-up" if args.route else "") if bands
                                        else f"frame-parallel x{world}"), "tile": "64x32 or 128x32, chosen by the library",
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "world_size_observed": observed_world,
                        "backend": (args.backend if world > 1 else None)},
@@ -660,6 +679,8 @@ def main():
             out["roofline_valu"] = vr
         if dflt_q:
             out["default_hw_queues"] = dflt_q
+        if bands and args.route:
+            out["routed_polys_per_frame_rank0"] = routed[0] // max(args.steps + args.warmup, 1)
         out.update(side)
         print_line = out
     else:

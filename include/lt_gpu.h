@@ -275,6 +275,22 @@ int lt_plane_normals_dev(lt_ctx *ctx, const int32_t *d_verts, int nv, const int3
 int lt_plane_normals(lt_ctx *ctx, const int32_t *verts, int nv, const int32_t *polys, int np,
                      const int32_t *polyverts, int npv, int32_t *plane_normals);
 
+/* Rows of the screen that each polygon of an object can touch: d_rows (DEVICE, int32[np][2]) gets
+ * {first row, last row}, or {1, 0} for a polygon that draws nothing.  For a sort-first split of one
+ * frame over several GPUs (lt_set_band): each GPU asks this for its share of the polygons, the GPUs
+ * exchange polygon indices by band, and each then submits only the polygons that can touch its band,
+ * in their original order.  No counterpart in the reference.  Where every vertex lies beyond the
+ * near plane the rows are those of the projected vertices, found as M_render_polygon finds them
+ * (view-volume test Clipp3D.cpp:46-58, T_perspective TransBs.cpp:425-432, T_normal_z_negative
+ * TransLn.cpp:218-223 at EngBase.cpp:433-470); a polygon that meets the near plane, or with data that
+ * lt_submit_object would report, gets every row: never fewer rows than the polygon is drawn on.
+ * Arguments as for lt_submit_object_dev; runs on the caller's stream. */
+int lt_polygon_rows_dev(lt_ctx *ctx, const int32_t m[12],
+                        const int32_t *d_verts, int nv,
+                        const int32_t *d_polys, int np,
+                        const int32_t *d_polyverts, int npv,
+                        int log_focus, int max_edges, int32_t *d_rows);
+
 /* M_render_polygon_object (EngPoly.cpp:499-525) for one object of np polygons, after
  * the host has built the matrix (T_set_self_rotation + T_cancatinate_self_world):
  * transform, then per polygon what M_render_polygon does (EngBase.cpp:379-552) --

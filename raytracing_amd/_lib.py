@@ -17,7 +17,7 @@ EXPORTS = [
     "lt_bind_framebuffer", "lt_set_band", "lt_set_pipelining", "lt_shade_object_dev", "lt_shade_object",
     "lt_plane_normals_dev", "lt_plane_normals", "lt_submit_lines_dev", "lt_submit_lines",
     "lt_set_clip_window", "lt_shade_points_dev", "lt_shade_points",
-    "lt_set_tile_width", "lt_submit_object_dev_noalloc", "lt_submit_screen_polys_prp",
+    "lt_set_tile_width", "lt_submit_object_dev_noalloc", "lt_submit_screen_polys_prp", "lt_polygon_rows_dev",
 ]
 
 
@@ -75,6 +75,7 @@ def lib():
     L.lt_submit_object.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
     L.lt_submit_object_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
     L.lt_submit_object_dev_noalloc.argtypes = L.lt_submit_object_dev.argtypes
+    L.lt_polygon_rows_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]
     L.lt_submit_screen_polys.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.lt_submit_screen_polys_prp.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32]
     L.lt_set_profiling.argtypes = [vp, i32]

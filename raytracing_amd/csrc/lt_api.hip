@@ -1005,6 +1005,29 @@ int lt_transform(lt_ctx *c, const int32_t m[12], const int32_t *d_from, int32_t 
     return LT_OK;
 }
 
+int lt_polygon_rows_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts, int nv, const int32_t *d_polys, int np,
+                        const int32_t *d_polyverts, int npv, int log_focus, int max_edges, int32_t *d_rows)
+{
+    if (!c) return LT_ERR_ARG;
+    if (np < 0 || nv < 0 || npv < 0) return fail(c, LT_ERR_ARG, "lt_polygon_rows_dev: negative count");
+    if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_polygon_rows_dev: log_focus %d outside 0..30", log_focus);
+    if (max_edges <= 0 || max_edges > 15) max_edges = 15;
+    if (np == 0) return LT_OK;
+    if (!d_verts || !d_polys || !d_polyverts || !d_rows) return fail(c, LT_ERR_ARG, "lt_polygon_rows_dev: NULL array");
+    int rc = use_device(c);
+    if (rc) return rc;
+    SetupArgs sa{};
+    sa.use_matrix = m ? 1 : 0;
+    if (m) for (int i = 0; i < 12; i++) sa.m[i] = m[i];
+    sa.verts = d_verts; sa.polys = d_polys; sa.polyverts = d_polyverts;
+    sa.np = np; sa.nv = nv; sa.npv = npv;
+    sa.log_focus = log_focus; sa.max_edges = max_edges;
+    sa.W = c->W; sa.H = c->H;
+    launch_polygon_rows(c->stream, sa, d_rows);
+    HIPCHK(c, hipGetLastError());
+    return LT_OK;
+}
+
 int lt_shade_object_dev(lt_ctx *c, const int32_t s9[9], int32_t x, int32_t y, int32_t z, const int32_t *d_verts, int nv,
                         const int32_t *d_normals, int nn, const int32_t *d_polys, int np, int32_t *d_polyverts,
                         const int32_t *d_polynormals, int npv, int32_t *d_polyaux, const lt_light *lights, int nlights)

@@ -165,6 +165,7 @@ void launch_shade(hipStream_t s, const ShadeArgs &a);
 void launch_shade_points(hipStream_t s, const ShadeArgs &a, const int *points, const int *normals, int n, int *rgb);
 
 void launch_transform(hipStream_t s, const int *m12_dev, const int *from, int *to, int n);
+void launch_polygon_rows(hipStream_t s, const SetupArgs &a, int *rows);
 void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
 // tile lists: count -> exclusive scan -> scatter (count must be zero before the call)
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tiles_x, int ntiles, unsigned *count,

@@ -2643,6 +2643,58 @@ void launch_transform(hipStream_t s, const int *m12, const int *from, int *to, i
     hipLaunchKernelGGL(transform_kernel, dim3((n + 255) / 256), dim3(256), 0, s, M, (const int4 *)from, to, n);
 }
 
+// Rows of the screen that a polygon of an object can touch, for routing polygons to the
+// GPUs of a sort-first split before any set-up: rows[p] = {first row, last row}, or {1, 0}
+// for a polygon that draws nothing.  Where every vertex lies beyond the near plane this is
+// exact arithmetic on the projected vertices -- the volume test (Clipp3D.cpp:46-58), the
+// projection (T_perspective, TransBs.cpp:425-432) and the facing test (T_normal_z_negative,
+// TransLn.cpp:218-223) as M_render_polygon makes them (EngBase.cpp:433-470); x and y clipping
+// only take rows away.  A polygon that meets the near plane, or whose data the set-up kernels
+// will have to report, gets every row.
+__global__ void __launch_bounds__(256) polygon_rows_kernel(SetupArgs a, int2 *__restrict__ rows)
+{
+    const int poly = blockIdx.x * blockDim.x + threadIdx.x;
+    if (poly >= a.np) return;
+    const int2 all = make_int2(0, a.H - 1), none = make_int2(1, 0);
+    const int4 pd = ((const int4 *)a.polys)[poly];
+    const int e = pd.z, first = pd.w;
+    if (e < 1 || e > a.max_edges || first < 0 || (long long)first + e + 1 > (long long)a.npv) { rows[poly] = all; return; }
+    int mn[3] = {INT_MAX, INT_MAX, INT_MAX}, mx[3] = {INT_MIN, INT_MIN, INT_MIN};
+    // tuples 0 .. e (the closing one repeats the first): view space
+    for (int i = 0; i <= e; i++) {
+        const int vi = a.polyverts[(size_t)(first + i) * 6];
+        if ((unsigned)vi >= (unsigned)a.nv) { rows[poly] = all; return; }
+        const int4 p = load_vertex(a, vi);
+        mn[0] = min(mn[0], p.x); mx[0] = max(mx[0], p.x);
+        mn[1] = min(mn[1], p.y); mx[1] = max(mx[1], p.y);
+        mn[2] = min(mn[2], p.z); mx[2] = max(mx[2], p.z);
+    }
+    if ((mx[2] < mn[0]) || (mx[2] < mn[1]) || (mx[2] < -mx[0]) || (mx[2] < -mx[1]) || (mx[2] <= 10)) { rows[poly] = none; return; }
+    if (mn[2] < 10) { rows[poly] = all; return; }
+    const int xc = a.W / 2, yc = a.H / 2;
+    int lo = INT_MAX, hi = INT_MIN, px[3] = {0, 0, 0}, py[3] = {0, 0, 0};
+    for (int i = 0; i <= e; i++) {
+        const int4 p = load_vertex(a, a.polyverts[(size_t)(first + i) * 6]);
+        const double rz = drcp(p.z);
+        const int x = wadd(persp_div(p.x, a.log_focus, p.z, rz), xc), y = wadd(persp_div(p.y, a.log_focus, p.z, rz), yc);
+        if (i < 3) { px[i] = x; py[i] = y; }
+        lo = min(lo, y); hi = max(hi, y);
+    }
+    if (e >= 2) {
+        const long long c = (long long)wsub(px[1], px[0]) * (long long)wsub(py[2], py[0]) -
+                            (long long)wsub(py[1], py[0]) * (long long)wsub(px[2], px[0]);
+        if (!(c < 0)) { rows[poly] = none; return; }
+    }
+    lo = max(lo, 0); hi = min(hi, a.H - 1);
+    rows[poly] = lo <= hi ? make_int2(lo, hi) : none;
+}
+
+void launch_polygon_rows(hipStream_t s, const SetupArgs &a, int *rows)
+{
+    if (a.np <= 0) return;
+    hipLaunchKernelGGL(polygon_rows_kernel, dim3((a.np + 255) / 256), dim3(256), 0, s, a, (int2 *)rows);
+}
+
 void launch_shade_points(hipStream_t s, const ShadeArgs &a, const int *points, const int *normals, int n, int *rgb)
 {
     if (n <= 0) return;

@@ -219,6 +219,16 @@ class Context:
                                               _dp(d_polyaux), d_polys.shape[0], _dp(d_polyverts),
                                               d_polyverts.shape[0], render_type, log_focus, force_linear, max_edges))
 
+    def polygon_rows_dev(self, d_verts, d_polys, d_polyverts, log_focus, matrix=None, max_edges=0):
+        """rows of the screen each polygon can touch: torch int32 [np][2] = {first, last}, {1, 0} for none
+        (for routing polygons to the GPUs of a sort-first split, raytracing_amd.bands.route)"""
+        import torch
+        m = _i32(IDENTITY if matrix is None else matrix)
+        rows = torch.empty((d_polys.shape[0], 2), dtype=torch.int32, device=d_polys.device)
+        self._chk(self.L.lt_polygon_rows_dev(self.h_ctx, _p(m), _dp(d_verts), d_verts.shape[0], _dp(d_polys), d_polys.shape[0],
+                                             _dp(d_polyverts), d_polyverts.shape[0], log_focus, max_edges, _dp(rows)))
+        return rows
+
     def submit_object_dev_noalloc(self, d_verts, d_polys, d_polyverts, render_type, log_focus, d_polyaux=None,
                                   matrix=None, force_linear=0, max_edges=0):
         """submit_object_dev through the static work array: no device allocation in the call"""

@@ -144,3 +144,98 @@ def test_unbind_returns_to_own_frame(env):
     ctx.bind_framebuffer(None, None)
     c2, z2 = ctx.readback()
     assert (c2 == own_c).all() and (z2 == own_z).all()
+
+
+# ---- routed set-up: lt_polygon_rows_dev + the band lists of raytracing_amd.bands
+
+def _host_rows(P, sc):
+    """rows of the projected vertices in Python integers where every vertex of a polygon lies
+    beyond the near plane (no volume test, no facing test: a superset of what the library
+    reports), the whole screen otherwise"""
+    v = P.transform(sc.matrix, sc.verts).astype(np.int64)
+    rows = np.zeros((sc.n_polys, 2), np.int64)
+    for p in range(sc.n_polys):
+        e, first = int(sc.polys[p, 2]), int(sc.polys[p, 3])
+        idx = sc.polyverts[first:first + e + 1, 0]
+        z = v[idx, 2]
+        if (z < 10).any():
+            rows[p] = (0, sc.height - 1)
+            continue
+        num = v[idx, 1] << sc.log_focus
+        y = np.sign(num) * (np.abs(num) // z) + sc.height // 2          # C division truncates
+        lo, hi = max(int(y.min()), 0), min(int(y.max()), sc.height - 1)
+        rows[p] = (lo, hi) if lo <= hi else (1, 0)
+    return rows
+
+
+def _routed(P, G, sc, world, clear, align=32):
+    """`world` ranks played one after the other on one GPU: each works out the rows of its share,
+    the lists are joined per band in rank order, and each band draws only its list"""
+    import torch
+    ctx = G.Context(sc.width, sc.height)
+    d = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (sc.verts, sc.polys, sc.polyverts)]
+    d_aux = torch.from_numpy(sc.polyaux).cuda() if sc.polyaux is not None else None
+    for h, (tex, lg) in enumerate(sc.textures):
+        ctx.texture_upload(h, tex, lg)
+    me = int(sc.polys[:, 2].max())
+    per_band = [[] for _ in range(world)]
+    all_rows = []
+    for k in range(world):
+        lo, hi = B.share(k, world, sc.n_polys)
+        rows = ctx.polygon_rows_dev(d[0], d[1][lo:hi], d[2], sc.log_focus, matrix=sc.matrix, max_edges=me)
+        all_rows.append(rows.cpu().numpy())
+        for r, l in enumerate(B.lists_by_band(rows, lo, world, sc.height, align)):
+            per_band[r].append(l)
+    c = np.full((sc.height, sc.width), -1, np.int32)
+    z = np.full((sc.height, sc.width), -1, np.int32)
+    frags, routed = 0, 0
+    for r, (y0, y1) in enumerate(B.all_bands(world, sc.height, align)):
+        if y0 >= y1:
+            continue
+        mine = torch.cat(per_band[r]).long()
+        routed += int(mine.numel())
+        ctx.set_band(y0, y1)
+        ctx.clear(P.cl_light(*clear))
+        ctx.reset_counters()
+        if mine.numel():
+            ctx.submit_object_dev(d[0], d[1][mine].contiguous(), d[2], sc.render_type, sc.log_focus,
+                                  d_polyaux=None if d_aux is None else d_aux[mine].contiguous(), matrix=sc.matrix,
+                                  force_linear=sc.force_linear, max_edges=me)
+        bc, bz = ctx.readback(check=False)
+        c[y0:y1], z[y0:y1] = bc[y0:y1], bz[y0:y1]
+        frags += ctx.counters()["fragments"]
+    ctx.close()
+    return c, z, frags, routed, np.concatenate(all_rows)
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_routed_bands_equal_whole_frame(env, world):
+    """each band sets up only the polygons routed to it and the frame is the whole frame's"""
+    P, G = env
+    sc = S.gen_c2(20000, 640, 480, 9, radius=24, seed=78)
+    oc, oz, ocn = _oracle(P, sc, CLEAR)
+    c, z, frags, routed, rows = _routed(P, G, sc, world, CLEAR)
+    assert (z == oz).all() and (c == oc).all()
+    assert frags == ocn["fragments"]
+    assert routed < sc.n_polys                     # half the soup faces away: fewer set-ups than polygons, bands and all
+    want = _host_rows(P, sc)
+    live = rows[:, 0] <= rows[:, 1]
+    assert live.any() and (~live).any()
+    assert np.array_equal(rows[live], want[live])   # where the library keeps a polygon, its rows are the projected vertices'
+
+
+def test_routed_bands_with_clipped_and_textured_polygons(env):
+    """near-plane and border contact, many-edged polygons, both texture mappers, draw-order fill"""
+    P, G = env
+    for seed in range(3):
+        sc = S.gen_fuzz_polys(120, 320, 200, 8, 7800 + seed, render_type=S.M_TEXTURED, textured=True, equal_lights=False,
+                              zrange=(12, 2000))
+        oc, oz, ocn = _oracle(P, sc, CLEAR)
+        c, z, frags, routed, rows = _routed(P, G, sc, 3, CLEAR, align=1)
+        assert (z == oz).all() and (c == oc).all()
+        assert frags == ocn["fragments"]
+    sc = S.gen_c3(30000, 1920, 1080, 10, radius=10, equal_lights=True, lin_percent=70, seed=0xC0FFEE91, regular_mapping=True)
+    oc, oz, ocn = _oracle(P, sc, CLEAR)
+    c, z, frags, routed, rows = _routed(P, G, sc, 4, CLEAR)
+    assert (z == oz).all() and (c == oc).all()
+    assert frags == ocn["fragments"]
