@@ -2366,6 +2366,9 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
         keys[ly * KW + lx] = depth_key(z, 0u);
     }
     for (int p = t; p < (RASTER_THREADS / 64) * TH; p += RASTER_THREADS) marks[p] = 0ull;
+    // Every thread refreshes its entry of the coarse table at the start of each round, with no
+    // barrier before other waves read it: until then the entry must not rule anything out.
+    zmax[t] = INT_MAX;
     __syncthreads();
 
     unsigned long long frags = 0;

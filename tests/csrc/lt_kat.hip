@@ -35,3 +35,27 @@ extern "C" int lt_kat_eval(int op, const long long *a, const long long *b, const
     if (e != hipSuccess) return (int)e;
     return (int)hipDeviceSynchronize();
 }
+
+// Fills the LDS of every CU with `value` (as many 64 KB workgroups as fit the chip, several
+// times over): what a later kernel finds in LDS words it has not written itself.
+__global__ void __launch_bounds__(256) lds_fill_kernel(int value, int *sink)
+{
+    extern __shared__ int lds_words[];
+    const int n = 64 * 1024 / 4;
+    for (int i = threadIdx.x; i < n; i += 256) lds_words[i] = value;
+    __syncthreads();
+    // keep the stores alive, and the workgroup resident for a moment so that others land on other CUs
+    int s = 0;
+    for (int i = threadIdx.x; i < n; i += 256 * 64) s += lds_words[i];
+    if (s == 0x7fffffff) *sink = s;
+}
+
+extern "C" int lt_kat_fill_lds(int value, int *d_sink)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)lds_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(lds_fill_kernel, dim3(256 * 2 * 8), dim3(256), 64 * 1024, 0, value, d_sink);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    return (int)hipDeviceSynchronize();
+}
