@@ -2099,25 +2099,28 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
         auto colours = [&](unsigned pass) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < SHORT; q++) col[q] = hc.z;
+            // every texel load of the span first (blocks of four pixels that no lane needs are skipped),
+            // so that they are in flight together; then the light
 #pragma unroll
             for (int g = 0; g < SHORT / 4; g++) {
                 if (__ballot((pass >> (4 * g)) & 0xfu) == 0ull) continue;
-                const int *tp[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    tp[q] = nullptr;
-                    if (((pass >> (4 * g + q)) & 1u) && ckind != KIND_FLAT)
-                        tp[q] = texel_address<NA>(a, hc, poly, beg + 4 * g + q, y, beg, end, S, I);
+                    if (((pass >> (4 * g + q)) & 1u) && ckind != KIND_FLAT) {
+                        const int *tp = texel_address<NA>(a, hc, poly, beg + 4 * g + q, y, beg, end, S, I);
+                        if (tp) col[4 * g + q] = *tp;
+                    }
                 }
-                int src[4];
+            }
 #pragma unroll
-                for (int q = 0; q < 4; q++) src[q] = tp[q] ? *tp[q] : hc.z;
+            for (int g = 0; g < SHORT / 4; g++) {
+                if (__ballot((pass >> (4 * g)) & 0xfu) == 0ull) continue;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int px = 4 * g + q;
                     if (NA > 1 && ckind != KIND_FLAT) {
                         const int kl = ckind >= KIND_TEX_LIN ? __popc(pass & ((1u << px) - 1u)) : px;
-                        col[px] = cl_light(src[q], wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16,
+                        col[px] = cl_light(col[px], wadd(S[1 % NA], wmul(kl, I[1 % NA])) >> 16,
                                            wadd(S[2 % NA], wmul(kl, I[2 % NA])) >> 16,
                                            wadd(S[3 % NA], wmul(kl, I[3 % NA])) >> 16);
                     }
@@ -2283,6 +2286,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
             // ---- colours: nothing shared is touched, the groups behind go on meanwhile
             attrs(pass != 0u || ((long_used >> lane) & 1ull));
             colours(pass);
+            // the first recorded chunks of long spans: their texel loads together, then the light
 #pragma unroll
             for (int q = 0; q < LONG_PRE; q++) {
                 lcol[q] = 0;
@@ -2290,8 +2294,27 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
                     const unsigned long long pm = (unsigned long long)(unsigned)RL((int)ent_lo, q) |
                                                   ((unsigned long long)(unsigned)RL((int)ent_hi, q) << 32);
                     const Span sp = span_of(RL(ent_tag, q) & 0xff);
+                    const int xb = RL(ent_xb, q);
+                    if ((pm >> lane) & 1ull) {
+                        const int *tp = texel_address<NA>(a, sp.h, sp.poly, xb + lane, y, sp.beg, sp.end, sp.S, sp.I);
+                        lcol[q] = tp ? *tp : sp.h.z;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < LONG_PRE; q++) {
+                if (q < nent) {
+                    const unsigned long long pm = (unsigned long long)(unsigned)RL((int)ent_lo, q) |
+                                                  ((unsigned long long)(unsigned)RL((int)ent_hi, q) << 32);
+                    const Span sp = span_of(RL(ent_tag, q) & 0xff);
                     const int xb = RL(ent_xb, q), cr = RL(ent_carry, q);
-                    if ((pm >> lane) & 1ull) lcol[q] = span_colour(sp, xb + lane, cr + __popcll(pm & lt_mask));
+                    const int bkind = (sp.h.w >> 8) & 0xff;
+                    if (((pm >> lane) & 1ull) && NA > 1 && bkind != KIND_FLAT) {
+                        const int kl = bkind >= KIND_TEX_LIN ? cr + __popcll(pm & lt_mask) : xb + lane - sp.beg;
+                        lcol[q] = cl_light(lcol[q], wadd(sp.S[1 % NA], wmul(kl, sp.I[1 % NA])) >> 16,
+                                           wadd(sp.S[2 % NA], wmul(kl, sp.I[2 % NA])) >> 16,
+                                           wadd(sp.S[3 % NA], wmul(kl, sp.I[3 % NA])) >> 16);
+                    }
                 }
             }
             // ---- colour writes in draw order: groups by turn, inside a group by sequence number
