@@ -197,11 +197,14 @@ def _routed(P, G, sc, world, clear, align=32):
         ctx.set_band(y0, y1)
         ctx.clear(P.cl_light(*clear))
         ctx.reset_counters()
+        # (the selected rows are read by the library's own streams: they live until the read-back)
+        sel_polys = d[1][mine].contiguous()
+        sel_aux = None if d_aux is None else d_aux[mine].contiguous()
         if mine.numel():
-            ctx.submit_object_dev(d[0], d[1][mine].contiguous(), d[2], sc.render_type, sc.log_focus,
-                                  d_polyaux=None if d_aux is None else d_aux[mine].contiguous(), matrix=sc.matrix,
+            ctx.submit_object_dev(d[0], sel_polys, d[2], sc.render_type, sc.log_focus, d_polyaux=sel_aux, matrix=sc.matrix,
                                   force_linear=sc.force_linear, max_edges=me)
         bc, bz = ctx.readback(check=False)
+        del sel_polys, sel_aux
         c[y0:y1], z[y0:y1] = bc[y0:y1], bz[y0:y1]
         frags += ctx.counters()["fragments"]
     ctx.close()
