@@ -484,7 +484,7 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     const BatchPlan pl = plan_batch(c, screen, dim, np, max_edges, 1u << 20, d_prp_src != nullptr);
     int rc;
     // batches whose work arrays stay small take four sets and both geometry streams in turns
-    const bool deep = c->pipelined && np <= (1 << 21) && pl.capacity <= (1ull << 27);
+    const bool deep = c->pipelined && np <= (1 << 24) && pl.capacity <= (1ull << 30);
     const int set = (int)(c->batch_no % (deep ? 4u : 2u));
     lt_ctx::Work &w = c->work[set];
     hipStream_t gs = (deep && (c->batch_no & 1u)) ? c->own_gs2 : c->gs, rs = c->rs;
