@@ -2263,7 +2263,13 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3,
 #pragma unroll
                         for (int d = 32; d > 0; d >>= 1) m = max(m, __shfl_xor(m, d));
                         if (lane == 0) zcoarse[cb + j] = m;
-                        if (!immediate && nent == 64) { go_immediate(); sp = span_of(src); }
+                        if (!immediate && nent == 64) {
+                            // the chunks of this span recorded so far are written with the rest
+                            long_seqs |= 1ull << seq;
+                            seq++;
+                            go_immediate();
+                            sp = span_of(src);
+                        }
                         if (!immediate) {
                             long_used |= 1ull << src;
                             if (lane == nent) {

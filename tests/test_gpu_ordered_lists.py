@@ -142,3 +142,62 @@ def test_list_overflow_is_reported(env):
     with pytest.raises(G.LtError) as e:
         ctx.flush()
     assert e.value.code == -4
+
+
+def _wide_quad(width, y0, y1, z, l0, l1):
+    t = np.zeros((5, 8), np.int32)
+    for k, (x, y) in enumerate([(0, y0), (width - 1, y0), (width - 1, y1), (0, y1)]):
+        li = l0 if x == 0 else l1
+        t[k] = (x, y, z, li << 16, (li // 2) << 16, (255 - li) << 16, (x * 3) << 16, (y * 5) << 16)
+    t[4] = t[0]
+    return (4, t, 0, 0)
+
+
+@pytest.mark.parametrize("nquads", [5, 6, 7, 8, 13])
+def test_chunk_records_overflow_inside_a_span(env, nquads):
+    """full-width quads, each nearer than the one before: ten 64-pixel chunks with passes a span.  With seven
+    quads the 64 chunk records of the group run out inside the nearest quad's span, and what was recorded of
+    that span must still be written (nothing covers it afterwards)"""
+    P, G = env
+    W, H = 640, 64
+    tex = S.make_texture(9, 6)
+    polys = [_wide_quad(W, 8, 40, -1000 - 1000 * k, 40 + 10 * k, 250 - 10 * k) for k in range(nquads)]
+    orc = P.Oracle(W, H)
+    orc.set_texture(0, tex, 6)
+    orc.clear(0, 0, 0, 0)
+    for (e, t, col, tx) in polys:
+        orc.g_polygon(8, t, colour=col, tex=0)
+    for mode in (1 | LISTS_ALWAYS, 1 | LISTS_NEVER):
+        ctx = G.Context(W, H)
+        ctx.texture_upload(0, tex, 6)
+        ctx.set_textured_order(mode)
+        ctx.clear(0)
+        ctx.submit_screen_polys(8, polys)
+        c, z = ctx.readback(check=False)
+        assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all(), mode
+        ctx.close()
+
+
+def test_prefixes_of_scenes_of_wide_polygons(env):
+    """the first k polygons of a scene, for many k: what a polygon writes is compared before later
+    polygons cover it (a whole scene of wide polygons hides most of its own draws)"""
+    P, G = env
+    W, H = 640, 96
+    for seed, radius, lin in ((6, 500, 90), (2, 400, 100), (3, 60, 70)):
+        sc = S.gen_c3(400, W, H, 8, radius=radius, equal_lights=False, lin_percent=lin, seed=0xC0FFEE00 + seed, regular_mapping=True)
+        ctx = G.Context(W, H)
+        orc = P.Oracle(W, H)
+        for h, (tex, lg) in enumerate(sc.textures):
+            ctx.texture_upload(h, tex, lg)
+            orc.set_texture(h, tex, lg)
+        ctx.set_textured_order(1 | LISTS_ALWAYS)
+        vv = P.transform(sc.matrix, sc.verts)
+        for k in list(range(1, 100, 3)) + list(range(100, 400, 11)):
+            orc.clear(0, 0, 0, 0)
+            orc.render_polys(vv, sc.polys[:k], sc.polyaux[:k], sc.polyverts, sc.render_type, sc.log_focus, sc.force_linear)
+            ctx.clear(0)
+            ctx.submit_object(sc.verts, sc.polys[:k], sc.polyverts, sc.render_type, sc.log_focus, polyaux=sc.polyaux[:k],
+                              matrix=sc.matrix, force_linear=sc.force_linear, max_edges=3)
+            c, z = ctx.readback(check=False)
+            assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all(), (seed, k)
+        ctx.close()
