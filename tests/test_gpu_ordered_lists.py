@@ -201,3 +201,40 @@ def test_prefixes_of_scenes_of_wide_polygons(env):
             c, z = ctx.readback(check=False)
             assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all(), (seed, k)
         ctx.close()
+
+
+def test_piles_of_overlapping_triangles(env):
+    """the same few pixels drawn over and over (every span of a group waits for the one before: more rounds
+    than a group numbers, so it ends with both turns held), now and then a wide triangle between them;
+    prefixes of the list, so that a draw is seen before the next one covers it"""
+    P, G = env
+    W, H = 128, 64
+    tex = S.make_texture(9, 6)
+    rng = np.random.default_rng(5)
+    for variant in (0, 4):
+        polys = []
+        for k in range(220):
+            cx, cy = 40 + (k % 3) * (variant % 3), 30 + (k % 2)
+            r = 5 if (k % 17 or variant < 3) else 60
+            t = np.zeros((4, 8), np.int32)
+            for j, (x, y) in enumerate([(cx - r, cy - r), (cx + r, cy), (cx - r // 2, cy + r)]):
+                t[j, :3] = (x, y, int(rng.integers(-50000, -100)) if j == 0 else t[0, 2])
+                t[j, 3:6] = rng.integers(0, 256, 3) << 16
+                t[j, 6:8] = rng.integers(0, 1000, 2) << 16
+            t[3] = t[0]
+            polys.append((3, t, 0, 0))
+        for mode in (1 | LISTS_ALWAYS, 1 | LISTS_NEVER):
+            ctx = G.Context(W, H)
+            ctx.texture_upload(0, tex, 6)
+            ctx.set_textured_order(mode)
+            for k in list(range(60, 221, 7)) + [220]:
+                orc = P.Oracle(W, H)
+                orc.set_texture(0, tex, 6)
+                orc.clear(0, 0, 0, 0)
+                for (e, t, col, tx) in polys[:k]:
+                    orc.g_polygon(8, t, colour=col, tex=0)
+                ctx.clear(0)
+                ctx.submit_screen_polys(8, polys[:k])
+                c, z = ctx.readback(check=False)
+                assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all(), (variant, mode, k)
+            ctx.close()
