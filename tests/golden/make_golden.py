@@ -525,39 +525,71 @@ def bench_frame():
 def stale_depth_cases():
     """Frames in which lines that the screen clips are drawn AFTER filled polygons: G_line clips with
     dimension 2 (GraphicsBase.cpp:191-193), so a clipped end point's depth is what the polygon
-    clips before it left in the clippers' static stores (Clipp2D.cpp:99-104).  Every case starts
-    with an object of many clipped polygons, which overwrites every store: the frames do not
-    depend on what ran before.  Steps as in wire_cases."""
+    clips before it left in the clippers' static stores (Clipp2D.cpp:99-104, 172-177).  Every case
+    draws, right after its clear, one quadrilateral that reaches beyond all four sides of the
+    screen: its clips write every one of the twelve stores (its top and bottom edges both x sides,
+    the x-clipped outline's two upright edges both y sides), so the frames do not depend on what
+    ran before the case.  Steps as in wire_cases."""
     w, h = WIRE_W, WIRE_H
     cases = {}
+
+    def overwrite_stores(k):
+        t = np.array([[-w - 7 * k, -h - 3, -11 - k], [2 * w + 5, -h - 5 * k, -23], [2 * w + 9 * k, 2 * h + 1, -37 - 2 * k],
+                      [-w - 1, 2 * h + 11 * k, -5], [0, 0, 0]], dtype=np.int32)
+        t[4] = t[0]
+        return ("gpolys", S.M_FLAT, [(4, t, 0x203040 + 0x050301 * k)])
     a = S.gen_fuzz_polys(180, w, h, 7, 9100, render_type=S.M_SHADED)
     b = S.gen_fuzz_polys(120, w, h, 7, 9101, render_type=S.M_FLAT)
-    cases["shaded_flat_lines"] = [("clear", 0x101820), ("object", a, S.M_SHADED, (3, 4, 5, 0, 0, 30)),
+    cases["shaded_flat_lines"] = [("clear", 0x101820), overwrite_stores(8), ("object", a, S.M_SHADED, (3, 4, 5, 0, 0, 30)),
                                   ("lines", wire_lines(9110, 300, -150, 200, -30000, -300)),
                                   ("object", b, S.M_FLAT, (250, 2, 9, 4, -3, 25)),
                                   ("lines", wire_lines(9111, 200, -90, 120, -30000, -300))]
     t = S.gen_fuzz_polys(160, w, h, 7, 9102, render_type=S.M_TEXTURED, textured=True, equal_lights=True, zrange=(12, 2000))
     wsc = S.gen_fuzz_polys(140, w, h, 7, 9103, render_type=S.M_FLAT)
-    cases["textured_wire_object"] = [("clear", 0x000030), ("object", t, S.M_TEXTURED, (1, 2, 3, 0, 0, 20)),
+    cases["textured_wire_object"] = [("clear", 0x000030), overwrite_stores(9), ("object", t, S.M_TEXTURED, (1, 2, 3, 0, 0, 20)),
                                      ("object", wsc, S.M_WIRE, (3, 4, 5, 0, 0, 30)),
                                      ("lines", wire_lines(9112, 250, -200, 250, -40000, -200)),
                                      ("object", a, S.M_SHADED, (9, 250, 3, -5, 2, 40)),
                                      ("object", wsc, S.M_WIRE, (250, 7, 1, 6, 0, 12))]
     g = S.gen_screen_polys(90, w, h, seed=9104, dim=6)
-    cases["screen_polys_lines"] = [("clear", 0), ("object", a, S.M_SHADED, (3, 4, 5, 0, 0, 30)), ("gpolys", 4, g),
+    cases["screen_polys_lines"] = [("clear", 0), overwrite_stores(10), ("object", a, S.M_SHADED, (3, 4, 5, 0, 0, 30)), ("gpolys", 4, g),
                                    ("lines", wire_lines(9113, 300, -120, 150, -50000, 50))]
+    # more of the same, other seeds: objects of every render type and line lists in turn
+    for k in range(8):
+        rt = (S.M_SHADED, S.M_FLAT, S.M_TEXTURED)[k % 3]
+        o1 = S.gen_fuzz_polys(150 + 10 * k, w, h, 7, 9200 + k, render_type=rt, textured=rt == S.M_TEXTURED, equal_lights=True,
+                              zrange=(12, 1500))
+        o2 = S.gen_fuzz_polys(60 + 15 * k, w, h, 7, 9300 + k, render_type=S.M_SHADED, max_edges=3 + k % 5)
+        steps = [("clear", 0x080808 * k), overwrite_stores(k), ("object", o1, rt, (k, 2 * k, 3 * k, k - 4, 3 - k, 20 + 3 * k)),
+                 ("lines", wire_lines(9400 + k, 150 + 20 * k, -160, 220, -45000, -100))]
+        if k % 2:
+            steps += [("object", o2, S.M_WIRE, (250 - k, 5, k, 2, -2, 15 + k)), ("object", o2, S.M_SHADED, (3, 250, 2 * k, 0, 1, 35)),
+                      ("lines", wire_lines(9500 + k, 120, -60, 140, -20000, -500))]
+        else:
+            steps += [("object", o2, S.M_SHADED, (k, 9, 250, -1, 2, 28)), ("object", o1, S.M_WIRE, (1, k, 5, 3, 0, 22))]
+        cases[f"mix_{k}"] = steps
     return cases
 
 
 def stale_depth_kats():
     """stale_depth_cases() drawn by the reference build: digests."""
-    out = {}
-    for name, steps in stale_depth_cases().items():
-        r = R.Ref(WIRE_W, WIRE_H)
-        for hnd, (tex, lg) in enumerate(_textures_of(steps)):
-            r.set_texture(hnd, tex, lg)
-        c, z = run_wire_case(steps, r)
-        out[name] = dict(colour=S.frame_digest(c), depth=S.frame_digest(z), drawn=int((c != c[0, 0]).sum()))
+    def draw(names):
+        out = {}
+        for name in names:
+            steps = cases[name]
+            r = R.Ref(WIRE_W, WIRE_H)
+            for hnd, (tex, lg) in enumerate(_textures_of(steps)):
+                r.set_texture(hnd, tex, lg)
+            c, z = run_wire_case(steps, r)
+            out[name] = dict(colour=S.frame_digest(c), depth=S.frame_digest(z), drawn=int((c != c[0, 0]).sum()))
+        return out
+
+    cases = stale_depth_cases()
+    out = draw(list(cases))
+    # the stores are process-wide: a case whose frame depended on the cases before it would
+    # come out differently in another order
+    again = draw(list(cases)[::-1])
+    assert all(again[n] == out[n] for n in cases), [n for n in cases if again[n] != out[n]]
     return out
 
 

@@ -83,6 +83,15 @@ def test_tracked_stores_match_the_reference_frames(eng, name, whole_objects):
     assert S.frame_digest(z) == GOLD[name]["depth"] and S.frame_digest(c) == GOLD[name]["colour"]
 
 
+@pytest.mark.parametrize("name", sorted(GOLD, reverse=True))
+def test_frames_do_not_depend_on_the_case_before(eng, name):
+    """the stores are process-wide; every case overwrites all of them first, so any order of cases gives
+    the reference's frames (here the reverse of the order above)"""
+    eng.lte_track_clipper_stores(1)
+    c, z = _run(eng, MG.stale_depth_cases()[name], name < "n")
+    assert S.frame_digest(z) == GOLD[name]["depth"] and S.frame_digest(c) == GOLD[name]["colour"]
+
+
 def test_untracked_lines_take_depth_zero(eng):
     """the default: the restatement's convention (depth 0 at a clipped end), not the reference's leftover"""
     import oracle.port as P
