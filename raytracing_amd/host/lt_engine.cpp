@@ -86,7 +86,11 @@ uint64_t texel_digest(const HW_pixel *t, int log_size)
     return h[0] ^ (h[1] << 1) ^ (h[2] << 2) ^ (h[3] << 3) ^ (uint64_t)log_size;
 }
 
-int texture_handle(HW_pixel *texels, int log_size)
+void run_queue();
+
+// `may_flush`: nothing of the draw that asks has been queued yet, so the open batch may be
+// submitted to free a handle.
+int texture_handle(HW_pixel *texels, int log_size, bool may_flush = false)
 {
     auto it = g_tex_handles.find(texels);
     if (it != g_tex_handles.end() && it->second.epoch == g_tex_epoch && it->second.log_size == log_size) return it->second.handle;
@@ -100,15 +104,36 @@ int texture_handle(HW_pixel *texels, int log_size)
         e.epoch = g_tex_epoch;
         return e.handle;
     }
-    if (g_next_tex >= LT_MAX_TEXTURES) HW_error((char *)"(GPU) too many textures.\n");
-    const int h = g_next_tex++;
-    chk(lt_texture_upload(g_ctx, h, texels, log_size));
+    int h;
+    if (g_next_tex < LT_MAX_TEXTURES) {
+        h = g_next_tex++;
+    } else {
+        // Every handle is taken (the reference knows a texture by its pointer and has no such limit):
+        // the address that has gone unused for longest gives up its handle and is forgotten -- a
+        // later draw with it uploads it again.  The textures of the batch being built keep theirs.
+        auto oldest = [&]() {
+            auto v = g_tex_handles.end();
+            for (auto i = g_tex_handles.begin(); i != g_tex_handles.end(); ++i)
+                if (i->second.epoch != g_tex_epoch && (v == g_tex_handles.end() || i->second.epoch < v->second.epoch)) v = i;
+            return v;
+        };
+        auto victim = oldest();
+        if (victim == g_tex_handles.end()) {
+            if (!may_flush) HW_error((char *)"(GPU) more than 64 textures in one batch.\n");
+            run_queue();
+            victim = oldest();
+        }
+        h = victim->second.handle;
+        g_tex_handles.erase(victim);
+    }
+    chk(lt_texture_upload(g_ctx, h, texels, log_size));       // waits for the batches that read the handle's old texels
     g_tex_handles[texels] = TexEntry{h, log_size, d, g_tex_epoch};
     return h;
 }
 
 void run_queue()
 {
+    bool submitted = true;
     if (q_kind == Q_SCREEN && !q_desc.empty() && q_type == LT_TEXTURED_PRP) {
         chk(lt_submit_screen_polys_prp(g_ctx, q_tuples.data(), (int)(q_tuples.size() / 8), q_desc.data(), q_prp.data(),
                                        (int)(q_desc.size() / 4), q_focus, q_max_edges));
@@ -122,9 +147,13 @@ void run_queue()
                              q_max_edges));
     } else if (q_kind == Q_LINES && !q_lines.empty()) {
         chk(lt_submit_lines(g_ctx, q_lines.data(), (int)(q_lines.size() / 8)));
+    } else {
+        submitted = false;
     }
     q_kind = Q_NONE;
-    g_tex_epoch++;
+    // The epoch only moves when a batch has gone out: a texture whose entry carries the current epoch
+    // may be named by the open batch and keeps its handle and its texels until that batch is submitted.
+    if (submitted) g_tex_epoch++;
     q_lines.clear();
     q_prp.clear();
     q_tuples.clear(); q_desc.clear(); q_verts.clear(); q_polys.clear(); q_aux.clear(); q_pv.clear();
@@ -249,7 +278,8 @@ void G_prp_textured_polygon(int *edges, int length, int *O, int *u, int *v, HW_p
                             int log_texture_scale)
 {
     need_ctx();
-    const int tex = texture_handle(texture, log_texture_size);
+    open_queue(Q_SCREEN, LT_TEXTURED_PRP);           // first: what it submits must not find this texture marked as in use
+    const int tex = texture_handle(texture, log_texture_size, true);
     queue_screen(LT_TEXTURED_PRP, G_LNG_TEXTURED, edges, length, 0, tex);
     const int32_t k[12] = {O[0], O[1], O[2], O[6], O[7], u[0], u[1], u[2], v[0], v[1], v[2], log_texture_scale};
     q_prp.insert(q_prp.end(), k, k + 12);
@@ -306,7 +336,9 @@ void G_shaded_polygon(int *edges, int length, HW_pixel colour)
 void G_lin_textured_polygon(int *edges, int length, HW_pixel *texture, int log_texture_size)
 {
     need_ctx();
-    queue_screen(LT_TEXTURED, G_LNG_TEXTURED, edges, length, 0, texture_handle(texture, log_texture_size));
+    open_queue(Q_SCREEN, LT_TEXTURED);
+    const int tex = texture_handle(texture, log_texture_size, true);
+    queue_screen(LT_TEXTURED, G_LNG_TEXTURED, edges, length, 0, tex);
 }
 
 // ------------------------------------------------------------------ transforms (TransBs.cpp / Trans.cpp)
@@ -610,6 +642,9 @@ void M_render_polygon(struct M_polygon *poly, int *vertices, int *colours, int *
         track_view_polygon(poly, vertices, colours, textures, type);
         if (type == M_WIRE) return;                  // drawn as host-clipped lines
     }
+    open_queue(Q_VIEW, type);
+    // (before anything of this polygon is queued: a new texture may have to submit the open batch for a handle)
+    if (poly->m_texture) texture_handle(poly->m_texture->m_texture_bytes, poly->m_texture->m_log_texture_size, true);
     open_queue(Q_VIEW, type);
     const int base = (int)(q_verts.size() / 4);
     M_polygon tmp = *poly;
@@ -1026,4 +1061,5 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
     chk(lt_submit_object(g_ctx, Tc, object->m_vertices, object->m_no_vertices, polys.data(), aux.data(),
                          object->m_no_polygons, pv.data(), (int)(pv.size() / 6), type, M_camera_log_focus,
                          M_force_linear_tmapping, me));
+    g_tex_epoch++;                                   // a batch has gone out, as in run_queue
 }

@@ -124,3 +124,41 @@ def test_texels_changed_in_place_are_seen(eng):
         c, z = _frame(eng)
         assert np.array_equal(z, orc.zbuf()) and np.array_equal(c, orc.cbuf()), rnd
         tex[:] = S.make_texture(99, lg)             # same address, other texels
+
+
+def test_more_texture_arrays_than_handles(eng):
+    """The reference knows a texture by its pointer and has no limit on their number; the library has
+    LT_MAX_TEXTURES handles.  The mirror hands the handle of the address unused for longest to a new
+    address (submitting the open batch first when every handle belongs to it): 150 arrays used by screen-level
+    polygons in one frame, then objects whose polygons use four of the earlier arrays each."""
+    import oracle.port as P
+    lg = 4
+    texs = [np.ascontiguousarray(S.make_texture(1000 + i, lg), dtype=np.int32) for i in range(150)]
+    polys = S.gen_screen_polys(150, W, H, seed=61, dim=8)
+    orc = P.Oracle(W, H)
+    orc.clear(0x101010, 255, 255, 255)
+    eng.lte_clear(0x101010, 255, 255, 255)
+    keep = []
+    for i, (e, t, col) in enumerate(polys):
+        slot = i % 64
+        orc.set_texture(slot, texs[i], lg)
+        orc.g_polygon(8, t, colour=col, tex=slot)
+        tt = np.ascontiguousarray(t, dtype=np.int32)
+        keep.append(tt)
+        eng.lte_set_texture(slot, _p(texs[i]), lg)
+        eng.lte_g_polygon(8, _p(tt), e, col, 0, 0, 0, slot)
+    for k in range(3):
+        sc = S.gen_fuzz_polys(80, W, H, 7, 4400 + k, render_type=S.M_TEXTURED, textured=True, equal_lights=True)
+        sc.polys[:, 1] = np.arange(sc.polys.shape[0]) % 4
+        obj = (k, 3, 5, 0, 0, 25 + 5 * k)
+        for j in range(4):
+            orc.set_texture(j, texs[10 * k + j], lg)
+            eng.lte_set_texture(j, _p(texs[10 * k + j]), lg)
+        m = P.make_matrix((0, 0, 0, 0, 0, 0), obj, 0)
+        orc.render_polys(P.transform(m, sc.verts), sc.polys, sc.polyaux, sc.polyverts, S.M_TEXTURED, sc.log_focus)
+        v, po, pa, pv = sc.verts.copy(), sc.polys.copy(), sc.polyaux.copy(), sc.polyverts.copy()
+        keep += [v, po, pa, pv]
+        eng.lte_render_object(_p(v), v.shape[0], _p(po), _p(pa), _p(pv), po.shape[0], S.M_TEXTURED, 0, 0, 0, 0, 0, 0, sc.log_focus,
+                              *obj[3:], *obj[:3])
+    c, z = _frame(eng)
+    assert np.array_equal(z, orc.zbuf()) and np.array_equal(c, orc.cbuf())
