@@ -47,7 +47,15 @@ constexpr int STATUS_SLOTS = 256;
 constexpr int MAX_DEVICES = 64;            // device indices the library keeps per-device state for
 constexpr int QUEUES = 64;                 // sub-queues between the fast and the general setup kernel
 constexpr int QUEUE_COUNT_STRIDE = 32;     // words between their counters (one 128-byte line each)
-constexpr int SETUP_FAST_THREADS = 256;
+// Workgroups of the fast set-up kernel.  Two waves (12 KB of LDS) and not four: while a fill is
+// running its workgroups hold most of a CU's LDS, and a small set-up workgroup of the batch
+// behind it still finds room beside them (C3 at 4K: 1.170 -> 1.148 ms per frame).
+constexpr int SETUP_FAST_THREADS = 128;
+// LDS that a fill launch asks for on top of its own when set-up chains of other batches run
+// beside it: three fill workgroups a CU instead of four, and what they leave goes to set-up
+// workgroups (C2-small with two frames in flight: 0.1306 -> 0.1271 ms per frame; the fill
+// with the chip to itself is 13 % slower that way, so only overlapped launches ask).
+constexpr unsigned FILL_OVERLAP_LDS = 6144;
 inline unsigned setup_queue_cap(int np)
 {
     unsigned blocks = (unsigned)((np + SETUP_FAST_THREADS - 1) / SETUP_FAST_THREADS);
@@ -171,7 +179,7 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
                     unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done);
-void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop);
+void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop, unsigned extra_lds = 0);
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands);   // textured batches only; `device` is current
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 

@@ -2799,7 +2799,9 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tile
 // `start` / `stop` (either may be null) ride on the kernel's own dispatch: they take its
 // start and completion without a marker of their own in the stream, which would hold the
 // stream for a few microseconds each.
-void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop)
+// `extra_lds`: dynamic LDS the launch reserves without using it (FILL_OVERLAP_LDS), which lowers
+// the number of fill workgroups a CU holds.
+void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop, unsigned extra_lds)
 {
     dim3 g(a.tiles_x * a.tiles_y), b(TH * (tile_w / 8));
     if (tile_w == 128) {
@@ -2807,9 +2809,9 @@ void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEv
         else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 128>), g, b, 0, s, start, stop, 0, a);
         else hipExtLaunchKernelGGL((raster_kernel<6, 128>), g, b, 0, s, start, stop, 0, a);
     } else {
-        if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1, 64>), g, b, 0, s, start, stop, 0, a);
-        else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 64>), g, b, 0, s, start, stop, 0, a);
-        else hipExtLaunchKernelGGL((raster_kernel<6, 64>), g, b, 0, s, start, stop, 0, a);
+        if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1, 64>), g, b, extra_lds, s, start, stop, 0, a);
+        else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 64>), g, b, extra_lds, s, start, stop, 0, a);
+        else hipExtLaunchKernelGGL((raster_kernel<6, 64>), g, b, extra_lds, s, start, stop, 0, a);
     }
 }
 
