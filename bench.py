@@ -631,7 +631,7 @@ def main():
                      "bin": 16 * sc.n_polys + 4 * refs, "scan": 16 * sc.n_polys}.get(dom, frame_bytes)
         kernel_ms = alone_ms if alone_ms else in_region_ms
         achieved = own_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_note = measured_traffic(args.workload, sc.n_polys, dom)
+        traffic, traffic_note = (None, None) if bands else measured_traffic(args.workload, sc.n_polys, dom)
         what = "Gouraud Z-buffered" if sc.render_type == 4 else ("textured" if sc.render_type == 8 else "flat")
         out = {
             "metric": "Z-tested shaded Mfragments/s + Mtris/s at 1080p/4K, 1/2/4/8 MI355X",
@@ -674,7 +674,8 @@ def main():
                                        "note": "two frames are in flight in the timed region: two launches of the kernel share the "
                                                "chip, so one launch lasts longer than a step"}},
         }
-        vr = valu_roofline(args.workload, sc.n_polys, dom, kernel_ms)
+        # (the committed counter pass is of whole frames on one GPU: no such line for a band of a frame)
+        vr = None if bands else valu_roofline(args.workload, sc.n_polys, dom, kernel_ms)
         if vr:
             out["roofline_valu"] = vr
         if dflt_q:
