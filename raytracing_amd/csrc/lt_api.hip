@@ -411,7 +411,8 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
     const bool band_lists = ordered_follows && wa.blist;
     const int order_force = (dim == 8 && c->order_mode == LT_ORDER_ALWAYS) ? 1 : 0;
     launch_binning(gs, wa.hdr, np, twl, tiles_x, ntiles, wa.tcount, wa.toffset, wa.tcursor, wa.list, capacity,
-                   screen ? nullptr : sa.queue_count, c->status, scan_ev, fused, geom_done);
+                   screen ? nullptr : sa.queue_count, c->status, scan_ev, fused, geom_done,
+                   ordered_follows ? order_flag : nullptr, order_gen, order_force);
     if ((rc = stage_end(c, 2, gs, &scan_idx))) return rc;
     if (timed(c, 3)) {
         lt_ctx::Span sp{3, scan_idx, 0};

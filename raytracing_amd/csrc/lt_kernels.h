@@ -178,7 +178,8 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a);
 // tile lists: count -> exclusive scan -> scatter (count must be zero before the call)
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done);
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done,
+                    const int *order_flag = nullptr, int order_gen = 0, int order_force = 0);
 void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop, unsigned extra_lds = 0);
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands);   // textured batches only; `device` is current
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);

@@ -1188,10 +1188,15 @@ __device__ __forceinline__ bool prim_tiles(const int4 h, int twl, int &tx0, int 
     return true;
 }
 
+// (`order_flag` non-null: a textured batch.  If its set-up has found that it must be filled in
+// draw order -- or the caller has asked for that, `order_force` -- the tile lists have no reader:
+// the tile fill returns at once and the draw-order kernels work from the headers.)
 __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
-                                                            int ntiles, unsigned *__restrict__ count)
+                                                            int ntiles, unsigned *__restrict__ count,
+                                                            const int *__restrict__ order_flag, int order_gen, int order_force)
 {
     __shared__ unsigned hist[BIN_MAX_TILES];
+    if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * BIN_CHUNK;
@@ -1213,9 +1218,11 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
 __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
                                                               int ntiles, const unsigned *__restrict__ offset,
                                                               unsigned *__restrict__ cursor, unsigned *__restrict__ list,
-                                                              unsigned long long capacity)
+                                                              unsigned long long capacity,
+                                                              const int *__restrict__ order_flag, int order_gen, int order_force)
 {
     __shared__ unsigned hist[BIN_MAX_TILES];      // count, then the chunk's base slot inside the tile's list
+    if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
     __syncthreads();
     const int base = blockIdx.x * BIN_CHUNK;
@@ -2780,18 +2787,19 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
 
 void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tiles_x, int ntiles, unsigned *count,
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
-                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done)
+                    unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done,
+                    const int *order_flag, int order_gen, int order_force)
 {
     const bool lds = ntiles <= BIN_MAX_TILES;
     if (np > 0 && !counted) {
-        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, twl, tiles_x, ntiles, count);
+        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, twl, tiles_x, ntiles, count, order_flag, order_gen, order_force);
         else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, twl, tiles_x, count);
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, cursor, ntiles, capacity, queue_count, status);
     if (after_scan) (void)hipEventRecord(after_scan, s);
     if (np > 0) {
         // `done` (may be null) is the scatter's own completion (see launch_raster)
-        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity);
+        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity, order_flag, order_gen, order_force);
         else hipExtLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, (const unsigned *)offset, cursor, list, capacity);
     }
 }
