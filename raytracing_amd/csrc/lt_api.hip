@@ -109,6 +109,7 @@ struct lt_ctx {
         bool in_use = false;
     } work[4];
     int last_set = 0;                  // the set the batch before took
+    bool fill_shares_chip = false;     // the caller submits faster than the chip draws: this batch's fill will have other batches' set-up beside it
     unsigned batch_no = 0;
     bool pipelined = true;
     hipStream_t own_gs = nullptr, own_gs2 = nullptr, own_rs = nullptr;    // internal streams (non-blocking)
@@ -447,7 +448,7 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
     ra.status = c->status;
     // A Gouraud or flat fill that shares the chip with the set-up chains of other batches leaves
     // them room in LDS (not the textured fill: measured slower with it, 1.148 -> 1.159 ms at 4K)
-    const unsigned fill_lds = (geom_done && !c->fragment_heavy && tile_w == TW_NARROW && dim != 8) ? FILL_OVERLAP_LDS : 0u;
+    const unsigned fill_lds = (geom_done && c->fill_shares_chip && tile_w == TW_NARROW && dim != 8) ? FILL_OVERLAP_LDS : 0u;
     // The fill's events are its own dispatch's where no other kernel follows it: its start
     // and end for the stage timing, else its completion as this work set's "free" signal.
     if (ordered_follows) {
@@ -507,6 +508,16 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
         // 2.3-2.5 ms overlapped), so there the set-up waits for the fill before it as well.
         lt_ctx::Work &prev = c->work[c->last_set];
         if (c->fragment_heavy && prev.in_use) HIPCHK(c, hipStreamWaitEvent(gs, prev.raster_done, 0));
+        // Is the fill of the batch before still on its way?  Then batches arrive faster than they are
+        // drawn, and while this one's fill runs the set-up of the next will want room beside it
+        // (FILL_OVERLAP_LDS).  A caller that waits for every frame gets the fill at full occupancy.
+        c->fill_shares_chip = false;
+        if (prev.in_use && !c->fragment_heavy) {
+            c->fill_shares_chip = hipEventQuery(prev.raster_done) == hipErrorNotReady;
+            (void)hipGetLastError();        // "not ready" is an answer, not an error
+        }
+    } else {
+        c->fill_shares_chip = false;
     }
     if ((rc = ensure(c, w.hdr, pl.hdr))) return rc;
     if ((rc = ensure(c, w.edges, pl.edges))) return rc;

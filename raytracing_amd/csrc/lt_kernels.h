@@ -54,7 +54,7 @@ constexpr int SETUP_FAST_THREADS = 128;
 // LDS that a fill launch asks for on top of its own when set-up chains of other batches run
 // beside it: three fill workgroups a CU instead of four, and what they leave goes to set-up
 // workgroups (C2-small with two frames in flight: 0.1306 -> 0.1271 ms per frame; the fill
-// with the chip to itself is 13 % slower that way, so only overlapped launches ask).
+// with the chip to itself is 13 % slower that way, so only launches that will be overlapped ask).
 constexpr unsigned FILL_OVERLAP_LDS = 6144;
 inline unsigned setup_queue_cap(int np)
 {
