@@ -1,0 +1,13 @@
+#!/bin/bash
+for rep in 1 2 3; do
+for v in "$@"; do
+  cp scratch/libltgpu_$v.so raytracing_amd/libltgpu.so || exit 1
+  timeout -k 10 120 python bench.py --workload c3 --steps 24 --warmup 3 --headline-only > gpurun_out/var_${v}_c3.log 2>&1 || { echo "FAILED $v"; tail -5 gpurun_out/var_${v}_c3.log; exit 1; }
+  python - <<PY
+import json
+l=[x for x in open("gpurun_out/var_${v}_c3.log") if x.startswith("{")][-1]
+d=json.loads(l); print("$v rep$rep c3 ms_per_step", d["ms_per_step"])
+PY
+done
+done
+cp scratch/libltgpu_cur.so raytracing_amd/libltgpu.so
