@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 // and an empty launch still costs its dispatch, several times over when the chip is busy
 // with the fill of the previous batch.
 template <int DIM>
-__global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_kernel(SetupArgs a)
+__device__ __forceinline__ void setup_queues(const SetupArgs &a)
 {
     if (blockIdx.y < QUEUES) {
         SetupArgs q = a;
@@ -1168,6 +1168,16 @@ __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_kernel(SetupArg
         }
     }
 }
+// One kernel per tuple size, because their register budgets differ.  While fills run, three or
+// four of their waves sit on every SIMD (86 to 106 VGPRs each) and a wave of this kernel has to
+// find room beside them: the flat and Gouraud sizes are held to a third of the register file
+// (the Gouraud one spills 21 registers for it; C2-small with two frames in flight 0.1243 ->
+// 0.1201 ms per frame).  The textured size needs all 256: held to 168 it spills 257 and C3 at 4K
+// goes from 1.13 to 1.21 ms.
+template <int DIM> __global__ void setup_queues_kernel(SetupArgs a);
+template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_kernel<3>(SetupArgs a) { setup_queues<3>(a); }
+template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_kernel<6>(SetupArgs a) { setup_queues<6>(a); }
+template <> __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_kernel<8>(SetupArgs a) { setup_queues<8>(a); }
 
 // ------------------------------------------------------------------ binning
 
@@ -1195,7 +1205,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
                                                             int ntiles, unsigned *__restrict__ count,
                                                             const int *__restrict__ order_flag, int order_gen, int order_force)
 {
-    __shared__ unsigned hist[BIN_MAX_TILES];
+    extern __shared__ unsigned hist[];          // ntiles words (the launch sizes it: a small request finds room beside running fills)
     if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
     __syncthreads();
@@ -1221,7 +1231,7 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__r
                                                               unsigned long long capacity,
                                                               const int *__restrict__ order_flag, int order_gen, int order_force)
 {
-    __shared__ unsigned hist[BIN_MAX_TILES];      // count, then the chunk's base slot inside the tile's list
+    extern __shared__ unsigned hist[];            // ntiles words: count, then the chunk's base slot inside the tile's list
     if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
     __syncthreads();
@@ -2792,14 +2802,14 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tile
 {
     const bool lds = ntiles <= BIN_MAX_TILES;
     if (np > 0 && !counted) {
-        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, hdr, np, twl, tiles_x, ntiles, count, order_flag, order_gen, order_force);
+        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, hdr, np, twl, tiles_x, ntiles, count, order_flag, order_gen, order_force);
         else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, twl, tiles_x, count);
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, cursor, ntiles, capacity, queue_count, status);
     if (after_scan) (void)hipEventRecord(after_scan, s);
     if (np > 0) {
         // `done` (may be null) is the scatter's own completion (see launch_raster)
-        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity, order_flag, order_gen, order_force);
+        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity, order_flag, order_gen, order_force);
         else hipExtLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, (const unsigned *)offset, cursor, list, capacity);
     }
 }
