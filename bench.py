@@ -547,14 +547,26 @@ def main():
             ctx.flush()                          # the band is complete before it is sent
             B.gather_bands([f_c, f_z], rank, world, sc.height)
 
-    # warm-up frames are timed stage by stage; the timed region then carries events only
-    # around the slowest kernel (events cost stream time: seven per frame were a tenth of it)
+    # Which stage is the slowest is found on a few frames on one stream, every stage timed: with
+    # two frames in flight the stages stretch each other and the order of their durations changes
+    # from run to run.  The warm-up frames proper follow, and the timed region then carries events
+    # only around that stage's kernel (events cost stream time: seven per frame were a tenth of it).
+    probe = not args.no_pipelining and not bands and not args.host_arrays
     ctx.set_profiling(True)
+    if probe:
+        ctx.set_pipelining(False)
+        for i in range(4):
+            step()
+            if i == 0:
+                ctx.stage_ms()                   # the first frame allocates and loads code: not representative
+        warm_stages, warm_submits = ctx.stage_ms()
+        ctx.set_pipelining(True)
     for i in range(args.warmup):
         step()
         if i == 0 and args.warmup > 1:
-            ctx.stage_ms()                       # the first frame allocates and loads code: not representative
-    warm_stages, warm_submits = ctx.stage_ms()
+            ctx.stage_ms()
+    if not probe:
+        warm_stages, warm_submits = ctx.stage_ms()
     dom = max(warm_stages, key=lambda k: warm_stages[k]) if warm_submits else "fill"
     ctx.reset_counters()
     frame_no[0] = 0
@@ -656,7 +668,8 @@ def main():
             "mfragments_per_s": round(frags / dt_max / 1e6, 3),
             "fragments_per_frame": frags // max(args.steps, 1) // (1 if bands else world),
             "stage_ms_per_frame": {k: round(v / max(warm_submits, 1), 4) for k, v in warm_stages.items()},
-            "stage_ms_measured_on": f"{warm_submits} warm-up frame(s), all stages timed",
+            "stage_ms_measured_on": (f"{warm_submits} frame(s) on one stream before the warm-up, all stages timed" if probe else
+                                     f"{warm_submits} warm-up frame(s), all stages timed"),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_note": traffic_note,
