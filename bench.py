@@ -425,6 +425,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg and the frame check")
     ap.add_argument("--no-side-lines", action="store_true", help="skip the c4 / c3_4k / default_hw_queues measurements")
     ap.add_argument("--headline-only", action="store_true", help="the timed region and nothing else")
+    ap.add_argument("--sample-every", type=int, default=0,
+                    help="time the slowest kernel inside the region on every Nth frame (0: every 4th, or every frame of a short region)")
     ap.add_argument("--hw-queues", type=int, default=8,
                     help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4; the library keeps four streams busy)")
     args = ap.parse_args()
@@ -572,8 +574,11 @@ def main():
     frame_no[0] = 0
     # ... and only around every fourth launch of it: an event holds its stream for a few
     # microseconds, which two-stream frames of under 0.2 ms feel
-    sample_every = 4 if args.steps >= 8 else 1
-    ctx.set_profiling(dom, every=sample_every)
+    sample_every = args.sample_every if args.sample_every > 0 else (4 if args.steps >= 8 else 1)
+    if args.sample_every < 0:
+        ctx.set_profiling(False)
+    else:
+        ctx.set_profiling(dom, every=sample_every)
     ctx.stage_ms()
 
     def barrier():
