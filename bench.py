@@ -339,12 +339,12 @@ def c4_side(ctx, torch, dist, rank, world, dev, d_verts, d_polys, d_pv, sc, fram
             "mtris_per_s": round(sc.n_polys * total / dt / 1e6, 3), "mfragments_per_s": round(frags / dt / 1e6, 3)}
 
 
-def c3_side(torch, dist, dev, local_rank, tris, q2_tris, frames=12):
+def c3_side(torch, dist, dev, local_rank, tris, q2_tris, frames=24):
     """the 4K workload beside the headline (one GPU): configuration 3, and its variant with
     differing vertex lights (filled in draw order)"""
     from raytracing_amd import gpu as G
     out = {}
-    for name, n, nf in (("c3", tris, frames), ("c3-q2", q2_tris, 4)):
+    for name, n, nf in (("c3", tris, frames), ("c3-q2", q2_tris, 8)):
         sc = make_scene(name, n)
         ctx = G.Context(sc.width, sc.height, device=local_rank)
         for h, (tex, lg) in enumerate(sc.textures):
