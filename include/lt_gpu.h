@@ -140,7 +140,10 @@ int lt_framebuffer(lt_ctx *ctx, int32_t **d_colour, int32_t **d_depth);
  * read the current frame); a frame that is cleared away without having been read is still
  * drawn in full.  Not used with a bound frame (lt_bind_framebuffer), with a band
  * (lt_set_band), without pipelining, or after lt_framebuffer has handed out the frame's
- * addresses.  Default on; 0 keeps every frame in one pair.  No counterpart in the reference. */
+ * addresses.  Default: on if the environment variable GPU_MAX_HW_QUEUES (HIP's number of hardware
+ * queues per process, read when HIP starts; 4 when unset) is 8 or more, else off -- the second
+ * frame needs streams with hardware queues of their own to pay; 1 / 0 here override that.
+ * No counterpart in the reference. */
 int lt_set_frame_overlap(lt_ctx *ctx, int on);
 /* Draw into caller-owned device arrays int32[height][width] (both, or both NULL to go
  * back to the context's own frame) instead of the arrays lt_ctx_create allocated: the

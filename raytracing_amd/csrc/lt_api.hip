@@ -4,6 +4,7 @@
 #include "lt_kernels.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
@@ -669,6 +670,15 @@ int lt_ctx_create(int device, int width, int height, lt_ctx **out)
     CREATECHK(hipStreamCreateWithFlags(&c->alt_rs, hipStreamNonBlocking));
     CREATECHK(hipStreamCreateWithFlags(&c->own_gs2, hipStreamNonBlocking));
     c->gs = c->own_gs; c->rs = c->own_rs;
+    // Two frames in flight keep four streams of the library busy beside the caller's.  HIP gives a
+    // process GPU_MAX_HW_QUEUES hardware queues (four unless the variable says otherwise, read when
+    // HIP starts) and lets streams share them; with four, two of these streams share one and the
+    // second frame costs more than it brings (0.169 against 0.163 ms per C2-small frame), so the
+    // default follows the variable.  lt_set_frame_overlap overrides it either way.
+    {
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        c->frame_overlap = q && atoi(q) >= 8;
+    }
     CREATECHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     CREATECHK(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
     for (lt_ctx::Work &w : c->work) {

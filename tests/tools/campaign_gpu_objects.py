@@ -2,6 +2,7 @@
 types, clip windows, both tile widths, draw-order modes, with and without pipelining) through the C-ABI and compares
 frames and counters with the CPU restatement.  Last run: 5000 cases, 0 differing."""
 import os, sys, time, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle.port as P

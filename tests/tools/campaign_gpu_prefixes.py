@@ -1,6 +1,7 @@
 """draw-order fill: frames of the first k polygons of scenes of wide polygons, for many k, against the CPU
 restatement -- what a polygon writes is checked before later polygons cover it"""
 import os, sys, time, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle.port as P

@@ -1,5 +1,6 @@
 """Campaign, not collected by pytest: prefixes of dense scenes (thousands of polygons a tile: coarse depth table, both tile\nwidths, draw-order lists) against the CPU restatement.  Last run: 316 frames, 0 differing."""
 import os, sys, time, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle.port as P

@@ -1,5 +1,6 @@
 """Campaign, not collected by pytest: frames of the first k polygons (k = 1..100) of N fuzz scenes of every render type against\nthe CPU restatement: a draw is checked before later polygons cover it.  Last run: N = 120, 12000 frames, 0 differing."""
 import os, sys, time, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle.port as P

@@ -9,6 +9,7 @@ the golden cases do.  Needs oracle/_ref (built by __graft_entry__.build()).
 Last run (800): 1592 frames against the reference build's, 0 differing; the reference stopped on 4 sequences."""
 import ctypes as C
 import os, sys, time, tempfile
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))

@@ -7,6 +7,7 @@ radii 2..200, under the animated batch's per-frame matrices (triangles through t
 two objects per frame; fuzz polygon objects at 160x120 and 200x150.  Needs oracle/_ref (built by
 __graft_entry__.build()).  Last run (400): 389 frames, 0 differing; the reference stopped on 11."""
 import os, sys, time, tempfile
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)

@@ -1,5 +1,6 @@
 """Campaign, not collected by pytest: `python tests/tools/campaign_gpu_wire.py N` draws N fuzz objects as wireframes (M_WIRE,\nclip windows included) through the C-ABI and compares with the CPU restatement.  Last run: 800 cases, 0 differing."""
 import os, sys, time, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle.port as P

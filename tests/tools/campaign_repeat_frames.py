@@ -3,6 +3,7 @@ the animated batch's, the 4K textured workload in both fill modes) hundreds of t
 the first: any rare run-to-run difference shows up as a count.  Last run: 2400 frames, 0 differing (the build before
 the coarse-table fix: one in a thousand of the animated batch's frames)."""
 import os, sys, time, numpy as np, torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from raytracing_amd import scenes as S, frames as F, gpu as G
 

@@ -5,6 +5,7 @@ and without pipelining and frame overlap), checks the first render of each again
 the frame REPS times more, comparing every result with the first.  A rare run-to-run difference (a race between
 batches, streams or work sets) shows up as a count.  Last run (60 300): 60 frames, all equal to the CPU restatement; 18000 repeat renders, 0 differing."""
 import os, sys, time, numpy as np
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import oracle.port as P
