@@ -55,7 +55,7 @@ constexpr int SETUP_FAST_THREADS = 128;
 // beside it: three fill workgroups a CU instead of four, and what they leave goes to set-up
 // workgroups (C2-small with two frames in flight: 0.1306 -> 0.1271 ms per frame; the fill
 // with the chip to itself is 13 % slower that way, so only launches that will be overlapped ask).
-constexpr unsigned FILL_OVERLAP_LDS = 6144;
+constexpr unsigned FILL_OVERLAP_LDS = 1024;
 inline unsigned setup_queue_cap(int np)
 {
     unsigned blocks = (unsigned)((np + SETUP_FAST_THREADS - 1) / SETUP_FAST_THREADS);
@@ -126,6 +126,7 @@ struct RasterArgs {
     const int *const *tex_ptr;     // device table of texture base pointers
     const int *tex_log;            // device table of log sizes
     int band_y0, band_y1;          // rows drawn by this context
+    int start_rank_shift;          // set by launch_raster: log2 of the device's CU count (0: no priority rotation)
     Status *status;
 };
 

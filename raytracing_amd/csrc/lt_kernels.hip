@@ -506,6 +506,10 @@ __device__ __forceinline__ const int4 *record_header(const int *edges, int npiec
 template <int DIM>
 __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArgs a)
 {
+    // The kernels of a batch's set-up chain run beside the fills of earlier batches, each waiting
+    // for the one before it: their waves take the highest wave priority, so that a SIMD shared
+    // with fill waves (which rotate through the priorities) serves the chain first.
+    __builtin_amdgcn_s_setprio(3);
     constexpr int NA = DIM - 2;
     constexpr int ESZ = edge_ints(NA);
     constexpr int RU = record_units(ESZ / 4);
@@ -1121,6 +1125,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
 template <int DIM, bool SCREEN>
 __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 {
+    __builtin_amdgcn_s_setprio(3);          // see setup_fast_kernel
     if (a.queue) {
         // second stage: only the polygons that the fast kernel passed on.  Sub-queue
         // blockIdx.y is shared by the few workgroups of row y of the grid, which stride
@@ -1144,6 +1149,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 template <int DIM>
 __device__ __forceinline__ void setup_queues(const SetupArgs &a)
 {
+    __builtin_amdgcn_s_setprio(3);          // see setup_fast_kernel
     if (blockIdx.y < QUEUES) {
         SetupArgs q = a;
         q.polys = a.sq_desc; q.polyverts = a.sq_tuples; q.polyaux = nullptr;
@@ -1205,6 +1211,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
                                                             int ntiles, unsigned *__restrict__ count,
                                                             const int *__restrict__ order_flag, int order_gen, int order_force)
 {
+    __builtin_amdgcn_s_setprio(3);          // see setup_fast_kernel
     extern __shared__ unsigned hist[];          // ntiles words (the launch sizes it: a small request finds room beside running fills)
     if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
@@ -1231,6 +1238,7 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__r
                                                               unsigned long long capacity,
                                                               const int *__restrict__ order_flag, int order_gen, int order_force)
 {
+    __builtin_amdgcn_s_setprio(3);          // see setup_fast_kernel
     extern __shared__ unsigned hist[];            // ntiles words: count, then the chunk's base slot inside the tile's list
     if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
@@ -1307,6 +1315,7 @@ __global__ void __launch_bounds__(1024) scan_kernel(unsigned *__restrict__ count
                                                     unsigned long long capacity, unsigned *__restrict__ queue_count,
                                                     Status *status)
 {
+    __builtin_amdgcn_s_setprio(3);          // see setup_fast_kernel
     __shared__ unsigned wsum[SCAN_MAX_STEPS * 16];
     __shared__ unsigned tsum[16];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1410,32 +1419,114 @@ __device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &
     return hit;
 }
 
+// The same closed form with everything that does not depend on the row made once per edge:
+//   P  = |dx| | |dy| << 15 | (dx >= 0) << 30 | (dy < 0) << 31     (edge_pack)
+//   hr = 0.5 / |dy| in double precision                          (1.0 for a horizontal edge)
+// Both quotients divide by 2*|dy|; floor(N / (2k)) = floor((N >> 1) / k) for N >= 0, and with
+// m = 2*(N >> 1) + 1 the product m * hr lies at least 1/(2k) away from every integer, far more
+// than its rounding error (m < 2^31, k < 2^15), so truncating it gives the quotient exactly:
+// one 24-bit multiply, two conversions each way and two f64 multiplies per (edge, row)
+// instead of a reciprocal and two corrected single-precision quotients.
+__device__ __forceinline__ int edge_pack(int xy1, int xy2)
+{
+    const int x1 = xy1 & 0xffff, y1 = (xy1 >> 16) & 0xffff, x2 = xy2 & 0xffff, y2 = (xy2 >> 16) & 0xffff;
+    const int dx = x2 - x1, dy = y2 - y1;
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    return adx | (ady << 15) | (dx >= 0 ? 1 << 30 : 0) | (dy < 0 ? (int)0x80000000 : 0);
+}
+__device__ __forceinline__ bool edge_row_pre(int xy1, int P, double hr, int y, int &ia, int &xa, int &ib, int &xb)
+{
+    const int x1 = xy1 & 0xffff, y1 = (int)((unsigned)xy1 >> 16);
+    const int adx = P & 0x7fff, ady = (P >> 15) & 0x7fff;
+    const int j = P < 0 ? y1 - y : y - y1;
+    const bool hit = (unsigned)j <= (unsigned)ady;
+    const bool xmaj = adx > ady;
+    // numerators halved (see above): y-major  adx*j + (ady >> 1)
+    //                                x-major  adx*j + ady + ((-adx - 1) >> 1)   (first point of row j)
+    //                                         the same + adx                    (first point of row j + 1)
+    const int K2 = 2 * (adx + ady + ((-adx - 1) >> 1)) + 1;
+    const int K1 = xmaj ? K2 - 2 * adx : (ady | 1);
+    const int t = __mul24(2 * adx, j);
+    const int q1 = (int)((double)(t + K1) * hr), qC = (int)((double)(t + K2) * hr);
+    const int A = j == 0 ? 0 : q1;                              // x distance of the row's first point from x1
+    const int B = j == ady ? adx : qC - 1;
+    const int ohi = xmaj ? B : A;
+    const int lo = xmaj ? A : j, hi = xmaj ? B : j;             // point indices of the row's two end points
+    const bool fwd = (P & (1 << 30)) != 0;
+    ia = fwd ? lo : hi;
+    ib = fwd ? hi : lo;
+    xa = fwd ? x1 + A : x1 - ohi;
+    xb = fwd ? x1 + ohi : x1 - A;
+    return hit;
+}
+
+// Reciprocals of 1..63 as {1/k, 0.5/k}, held in LDS by the tile fill: the divisor of a row's
+// increments is its span and the divisor of an edge's point indices is twice its height, both
+// short for small polygons; larger ones take drcp().  Entry 0 is {1, 0.5} and never used as a
+// divisor.  The values are drcp()'s, so quotients do not depend on which way they were found.
+__device__ __forceinline__ void fill_rcp_table(double2 *lut, int t)
+{
+    if (t < 64) {
+        const double r = drcp(t > 0 ? t : 1);
+        lut[t] = make_double2(r, 0.5 * r);
+    }
+}
+__device__ __forceinline__ double2 rcp_pair(const double2 *lut, int d)         // d >= 1
+{
+    double2 l = lut[d < 64 ? d : 63];
+    if (__ballot(d >= 64)) {
+        int big = d;
+        asm volatile("" : "+v"(big));        // keeps the reciprocal inside this branch: as straight-line code it would cost every row more than the table saves
+        if (big >= 64) { l.x = drcp(big); l.y = 0.5 * l.x; }
+    }
+    return l;
+}
+// trunc(n / d) given rcp_pair(d)
+__device__ __forceinline__ int tdivp(int n, const double2 rp) { return (int)fma((double)n, rp.x, n < 0 ? -rp.y : rp.y); }
+
 // Row ends with all NA interpolated values (used by the colour pass).
 template <int NA>
 __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, int poly, int ne, int y, int &beg,
-                                         int &end, int (&S)[NA], int (&E)[NA], const int2 *pre = nullptr)
+                                         int &end, int (&S)[NA], int (&E)[NA], const int2 *pre = nullptr,
+                                         const double2 *lut = nullptr)
 {
     constexpr int ESZ = edge_ints(NA);
     int bx = INT_MAX, ex = INT_MIN, be = 0, bi = 0, ee = 0, ei = 0;
-    // `pre`: coordinates of edges 0..2 already fetched by the caller
+    // `pre`: coordinates of edges 0..2 already fetched by the caller; `lut`: the caller's
+    // reciprocal table (fill_rcp_table), which selects the form with per-edge constants
     int first = 0;
     if (pre) {
 #pragma unroll
         for (int e = 0; e < 3; e++) {
             int ia, xa, ib, xb;
-            if (e < ne && edge_row(pre[e].x, pre[e].y, y, ia, xa, ib, xb)) {
+            bool hit;
+            if (lut) {
+                const int P = edge_pack(pre[e].x, pre[e].y);
+                const int ady = (P >> 15) & 0x7fff;
+                hit = edge_row_pre(pre[e].x, P, rcp_pair(lut, ady > 0 ? ady : 1).y, y, ia, xa, ib, xb);
+            } else {
+                hit = edge_row(pre[e].x, pre[e].y, y, ia, xa, ib, xb);
+            }
+            if (e < ne && hit) {
                 if (xa < bx) { bx = xa; be = e; bi = ia; }
                 if (ex < xb) { ex = xb; ee = e; ei = ib; }
             }
         }
         first = 3;
     }
-    for (int e = first; e < ne; e++) {
-        const int2 xy = *(const int2 *)edge_piece(edges, np, ESZ / 4, e, 0, poly);
-        int ia, xa, ib, xb;
-        if (!edge_row(xy.x, xy.y, y, ia, xa, ib, xb)) continue;
-        if (xa < bx) { bx = xa; be = e; bi = ia; }
-        if (ex < xb) { ex = xb; ee = e; ei = ib; }
+    for (int e0 = first; e0 < ne; e0 += 4) {
+        // four edges' coordinates per memory round trip (see depth_row_mem)
+        int2 x4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x4[k] = e0 + k < ne ? *(const int2 *)edge_piece(edges, np, ESZ / 4, e0 + k, 0, poly) : make_int2(0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int ia, xa, ib, xb;
+            if (e0 + k < ne && edge_row(x4[k].x, x4[k].y, y, ia, xa, ib, xb)) {
+                if (xa < bx) { bx = xa; be = e0 + k; bi = ia; }
+                if (ex < xb) { ex = xb; ee = e0 + k; ei = ib; }
+            }
+        }
     }
     if (bx == INT_MAX) return false;
     int rb[ESZ], re[ESZ];
@@ -1547,16 +1638,57 @@ __device__ __forceinline__ bool depth_row3(const Edge4 (&ed)[3], int ne, int y, 
     return true;
 }
 
+// The same from edges with their per-edge constants (edge_row_pre); an absent edge is one
+// that no row hits.  The span's reciprocal comes from the table.
+struct EdgeP { int xy1, P, z0, zi; double hr; };
+
+__device__ __forceinline__ bool depth_row3_pre(const EdgeP (&ed)[3], int y, const double2 *lut, int &beg, int &end, int &zs,
+                                               int &zi)
+{
+    int bx = INT_MAX, ex = INT_MIN;
+    int bz0 = 0, bzi = 0, bi = 0, ez0 = 0, ezi = 0, ei = 0;
+#pragma unroll
+    for (int e = 0; e < 3; e++) {
+        int ia, xa, ib, xb;
+        const bool hit = edge_row_pre(ed[e].xy1, ed[e].P, ed[e].hr, y, ia, xa, ib, xb);
+        const bool tb = hit && xa < bx, te = hit && ex < xb;
+        bx = tb ? xa : bx; bz0 = tb ? ed[e].z0 : bz0; bzi = tb ? ed[e].zi : bzi; bi = tb ? ia : bi;
+        ex = te ? xb : ex; ez0 = te ? ed[e].z0 : ez0; ezi = te ? ed[e].zi : ezi; ei = te ? ib : ei;
+    }
+    if (bx == INT_MAX) return false;
+    const int sz = wadd(bz0, wmul(bi, bzi)), ez = wadd(ez0, wmul(ei, ezi));
+    int span = ex - bx;
+    if (span == 0) span = 1;
+    beg = bx; end = ex; zs = sz;
+    zi = tdivp(wsub(ez, sz), rcp_pair(lut, span));
+    return true;
+}
+
 __device__ __forceinline__ bool depth_row_mem(const int *__restrict__ edges, int npieces, int np, int poly, int ne, int y,
                                               int &beg, int &end, int &zs, int &zi)
 {
     int bx = INT_MAX, ex = INT_MIN, sz = 0, ez = 0;
-    for (int e = 0; e < ne; e++) {
-        const int4 r = *edge_piece(edges, np, npieces, e, 0, poly);
-        int ia, xa, ib, xb;
-        if (!edge_row(r.x, r.y, y, ia, xa, ib, xb)) continue;
-        if (xa < bx) { bx = xa; sz = wadd(r.z, wmul(ia, r.w)); }
-        if (ex < xb) { ex = xb; ez = wadd(r.z, wmul(ib, r.w)); }
+    // the coordinates of four edges at a time are fetched together, then the depth walk of the
+    // two edges that hold the row's ends: polygons cut by a screen border have four to seven
+    // edges, and one memory round trip per edge made the tiles along those borders the slowest
+    int be = 0, bi = 0, ee = 0, ei = 0;
+    for (int e0 = 0; e0 < ne; e0 += 4) {
+        int2 x4[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x4[k] = e0 + k < ne ? *(const int2 *)edge_piece(edges, np, npieces, e0 + k, 0, poly) : make_int2(0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int ia, xa, ib, xb;
+            if (e0 + k < ne && edge_row(x4[k].x, x4[k].y, y, ia, xa, ib, xb)) {
+                if (xa < bx) { bx = xa; be = e0 + k; bi = ia; }
+                if (ex < xb) { ex = xb; ee = e0 + k; ei = ib; }
+            }
+        }
+    }
+    if (bx != INT_MAX) {
+        const int2 zb = ((const int2 *)edge_piece(edges, np, npieces, be, 0, poly))[1], ze = ((const int2 *)edge_piece(edges, np, npieces, ee, 0, poly))[1];
+        sz = wadd(zb.x, wmul(bi, zb.y));
+        ez = wadd(ze.x, wmul(ei, ze.y));
     }
     if (bx == INT_MAX) return false;
     int span = ex - bx;
@@ -2389,12 +2521,25 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
     // whose smallest depth is greater than the entry cannot lower any key there and is
     // skipped without touching the keys.  Its fragments are counted all the same.
     __shared__ int zmax[TH * (TW / 8)];
-    __shared__ int4 stage[RASTER_THREADS * 4];       // per wave: 64 polygons x {edge0, edge1, edge2, {poly, ne, r0, offset}}
+    // per wave: 64 polygons x {edge 0, edge 1, edge 2 as {x1|y1<<16, edge_pack, Zstart, Zinc}, {hr of edges 0 and 1},
+    // {hr of edge 2, polygon, edges | first row << 5 | row offset << 19}}
+    __shared__ int4 stage[RASTER_THREADS * 5];
+    __shared__ double2 rlut[64];
     // per wave: one bit per row of a round (64 polygons x TH rows), set at the last row of every polygon
     __shared__ unsigned long long marks[(RASTER_THREADS / 64) * (TH * 64 / 64)];
 
     const int t = threadIdx.x, lane = t & 63;
-    const int tile = blockIdx.x;
+    // Workgroups start in index order and a CU serves its oldest waves first, so the tiles that
+    // take longest should come first: those of the two border columns, where polygons cut by
+    // the x clip have more than three edges and rows cost a memory round trip.  Measured on
+    // one million small triangles at 1080p: started last, such tiles ended 12-20 us after all
+    // others and set the kernel's duration.
+    int tile = blockIdx.x;
+    if (a.tiles_x >= 3) {
+        const int nb = 2 * a.tiles_y;
+        if (tile < nb) tile = (tile >> 1) * a.tiles_x + ((tile & 1) ? a.tiles_x - 1 : 0);
+        else { const int q = tile - nb, w = a.tiles_x - 2; tile = (q / w) * a.tiles_x + 1 + q % w; }
+    }
     const int tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
     const unsigned lbeg = a.tile_offset[tile];
     unsigned lcnt = a.tile_fill[tile];
@@ -2415,6 +2560,7 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
     // Every thread refreshes its entry of the coarse table at the start of each round, with no
     // barrier before other waves read it: until then the entry must not rule anything out.
     zmax[t] = INT_MAX;
+    fill_rcp_table(rlut, t);
     __syncthreads();
 
     unsigned long long frags = 0;
@@ -2495,7 +2641,9 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
             // similar length.  `rank` is a polygon's place in that order (polygons without
             // rows come last), and rows are numbered in that order.
             const int wdt = cx1 - cx0 + 1;
-            const int cls = !owns ? 16 : (wdt <= 16 ? (wdt - 1) >> 1 : 8 + min((wdt - 17) >> 3, 7));
+            // polygons with more than three edges take the last class: their rows fetch edges from
+            // memory, and together at the end of the order they make few steps pay for that path
+            const int cls = !owns ? 16 : (ne > 3 ? 15 : (wdt <= 16 ? (wdt - 1) >> 1 : 8 + min((wdt - 17) >> 3, 7)));
             int rank = 0, placed = 0;
 #pragma unroll
             for (int b = 0; b <= 16; b++) {
@@ -2513,37 +2661,63 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
             }
             const int total = __shfl(incl_s, 63);
             const int incl = __builtin_amdgcn_ds_bpermute(rank << 2, incl_s);
-            int4 *st = stage + (size_t)(t & ~63) * 4;       // this wave's 64 x 4 pieces
+            int4 *st = stage + (size_t)(t & ~63) * 5;       // this wave's 64 x 5 pieces
             unsigned long long *mk = marks + (t >> 6) * TH;
             const int last = incl - 1;
             if (owns) {
-                st[rank * 4 + 0] = make_int4(ed[0].xy1, ed[0].xy2, ed[0].z0, ed[0].zi);
-                st[rank * 4 + 1] = make_int4(ed[1].xy1, ed[1].xy2, ed[1].z0, ed[1].zi);
-                st[rank * 4 + 2] = make_int4(ed[2].xy1, ed[2].xy2, ed[2].z0, ed[2].zi);
-                st[rank * 4 + 3] = make_int4(poly, ne, r0, incl - cnt);
+                // what the rows of this polygon share is made here, once: the packed deltas and
+                // the reciprocal of each edge (an edge the polygon does not have gets a first
+                // row that no row of the screen equals)
+                int P[3];
+                double hr[3];
+#pragma unroll
+                for (int e = 0; e < 3; e++) {
+                    P[e] = e < ne ? edge_pack(ed[e].xy1, ed[e].xy2) : 0;
+                    const int ady = (P[e] >> 15) & 0x7fff;
+                    hr[e] = rcp_pair(rlut, ady > 0 ? ady : 1).y;
+                    st[rank * 5 + e] = make_int4(e < ne ? ed[e].xy1 : (int)0xffff0000, P[e], ed[e].z0, ed[e].zi);
+                }
+                st[rank * 5 + 3] = make_int4(__double2loint(hr[0]), __double2hiint(hr[0]), __double2loint(hr[1]), __double2hiint(hr[1]));
+                st[rank * 5 + 4] = make_int4(__double2loint(hr[2]), __double2hiint(hr[2]), poly, ne | (r0 << 5) | ((incl - cnt) << 19));
                 atomicOr(&mk[last >> 6], 1ull << (last & 63));
             }
             LDS_WAVE_SYNC();
             for (int rb = 0; rb < total; rb += 64) {
+                // A SIMD issues from its oldest wave first, so of the workgroups that share a CU the
+                // first to start would run at its own pace and the last would be left to finish
+                // alone, one wave a SIMD, which cannot keep the SIMD busy (lifetimes of 50, 59, 70
+                // and 83 us for the four measured).  Every step takes the next of the four wave
+                // priorities, offset by the workgroup's place in the start order: each wave leads a
+                // quarter of the time and the four end within a few microseconds of each other.
+                switch ((a.start_rank_shift ? (int)(blockIdx.x >> a.start_rank_shift) + (rb >> 6) + (int)rd : 0) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+                }
                 const int r = rb + lane;
                 // polygons that end before this step's first row, then those that end inside the step before r
                 const int before = __popcll(__ballot(owns && last < rb));
                 const unsigned long long word = mk[rb >> 6];
                 if (r < total) {
                     const int lo = before + __builtin_amdgcn_mbcnt_hi((unsigned)(word >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)word, 0u));
-                    const int4 ow = st[lo * 4 + 3];
-                    const int opoly = ow.x, one = ow.y, y = ow.z + (r - ow.w);
+                    const int4 ow = st[lo * 5 + 4];
+                    const int opoly = ow.z, one = ow.w & 31, y = ((ow.w >> 5) & 0x3fff) + (r - (int)((unsigned)ow.w >> 19));
                     const unsigned id = (unsigned)opoly + 1u;
                     int beg, end, zs, zi;
                     bool ok;
                     if (one <= 3) {
-                        Edge4 oe[3];
+                        EdgeP oe[3];
+                        const int4 h01 = st[lo * 5 + 3];
 #pragma unroll
                         for (int e = 0; e < 3; e++) {
-                            const int4 q = st[lo * 4 + e];
-                            oe[e].xy1 = q.x; oe[e].xy2 = q.y; oe[e].z0 = q.z; oe[e].zi = q.w;
+                            const int4 q = st[lo * 5 + e];
+                            oe[e].xy1 = q.x; oe[e].P = q.y; oe[e].z0 = q.z; oe[e].zi = q.w;
                         }
-                        ok = depth_row3(oe, one, y, beg, end, zs, zi);
+                        oe[0].hr = __hiloint2double(h01.y, h01.x);
+                        oe[1].hr = __hiloint2double(h01.w, h01.z);
+                        oe[2].hr = __hiloint2double(ow.y, ow.x);
+                        ok = depth_row3_pre(oe, y, rlut, beg, end, zs, zi);
                     } else {
                         ok = depth_row_mem(a.edges, ESZ / 4, a.np, opoly, one, y, beg, end, zs, zi);
                     }
@@ -2590,6 +2764,7 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
     }
     __syncthreads();
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- colour pass + tile out.  Pixels are taken four at a time per lane so that the
     // four winners' headers and edge coordinates are fetched together (one memory round
     // trip for the group, a second one for the winning edges' values).
@@ -2638,12 +2813,12 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
             int c = h.z;
             if (NA > 1 && kind != KIND_FLAT) {
                 int S[NA], E[NA], I[NA], beg = 0, end = 0;
-                row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E, xy[g]);
+                row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E, xy[g], rlut);
                 int span = end - beg;
                 if (span == 0) span = 1;
-                const double rs = drcp(span);
+                const double2 rs = rcp_pair(rlut, span);
 #pragma unroll
-                for (int q = 0; q < NA; q++) I[q] = tdivr(wsub(E[q], S[q]), rs);
+                for (int q = 0; q < NA; q++) I[q] = tdivp(wsub(E[q], S[q]), rs);
                 if (NA == 6 && kind >= KIND_TEX_LIN && ((I[1 % NA] | I[2 % NA] | I[3 % NA]) != 0)) qrows++;
                 c = pixel_colour<NA>(a, h, poly, gx, gy, beg, end, S, I, gx - beg);
             }
@@ -2819,8 +2994,23 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tile
 // stream for a few microseconds each.
 // `extra_lds`: dynamic LDS the launch reserves without using it (FILL_OVERLAP_LDS), which lowers
 // the number of fill workgroups a CU holds.
-void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop, unsigned extra_lds)
+void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a_in, hipEvent_t start, hipEvent_t stop, unsigned extra_lds)
 {
+    // log2 of the CU count (rounded down): workgroup index >> that is the workgroup's place among
+    // those that start on one CU, near enough for the priority rotation of the depth pass
+    static std::atomic<int> cu_shift[MAX_DEVICES];
+    RasterArgs a = a_in;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAX_DEVICES) {
+        int sh = cu_shift[dev].load(std::memory_order_relaxed);
+        if (sh == 0) {
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 2) ncu = 2;
+            sh = 31 - __builtin_clz((unsigned)ncu);
+            cu_shift[dev].store(sh, std::memory_order_relaxed);
+        }
+        a.start_rank_shift = sh;
+    }
     dim3 g(a.tiles_x * a.tiles_y), b(TH * (tile_w / 8));
     if (tile_w == 128) {
         if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1, 128>), g, b, 0, s, start, stop, 0, a);
