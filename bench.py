@@ -69,17 +69,46 @@ def make_scene(workload, tris):
 
 
 STAGE_KERNEL = {"fill": "raster_kernel<4, 64>", "setup": "setup_fast_kernel", "bin": "scatter_kernel", "scan": "count_kernel"}
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_c2small.json")
+KERNEL_SOURCES = ["lt_kernels.hip", "lt_api.hip", "lt_kernels.h", "lt_math.h"]
+
+
+def kernel_source_sha():
+    """sha256 over the sources the HIP library is built from (the counter passes under profiles/ record it:
+    counters quoted in the line must belong to the code that is being timed)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "raytracing_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def load_pmc(workload, tris):
+    """the committed counter passes, or (None, why) when they are absent, of another workload, or of other sources"""
+    if workload != "c2-small" or tris != 1_000_000:
+        return None, "the committed counter passes are of the c2-small frame of 1M triangles"
+    if not os.path.exists(PMC_FILE):
+        return None, f"{os.path.relpath(PMC_FILE, ROOT)} is absent"
+    pmc = json.load(open(PMC_FILE))
+    want = pmc.get("_meta", {}).get("source_sha256")
+    have = kernel_source_sha()
+    if want != have:
+        return None, (f"{os.path.relpath(PMC_FILE, ROOT)} was collected on other kernel sources (sha256 {str(want)[:12]}.. there, "
+                      f"{have[:12]}.. here): run profiles/collect.sh again")
+    return pmc, None
 
 
 def measured_traffic(workload, tris, stage):
     """HBM-side bytes per launch of the stage's main kernel from the committed counter passes
     (profiles/: separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of this
     benchmark, KiB per launch).  Only for the workload the passes were taken on."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_c2small.json")
-    if workload != "c2-small" or tris != 1_000_000 or not os.path.exists(path):
-        return None, None
-    pmc = json.load(open(path))
+    pmc, why = load_pmc(workload, tris)
+    if pmc is None:
+        return None, why
     for name, ctrs in pmc.items():
+        if name.startswith("_"):
+            continue
         if STAGE_KERNEL.get(stage, "?") in name and "FETCH_SIZE" in ctrs and "WRITE_SIZE" in ctrs:
             f, w = ctrs["FETCH_SIZE"]["mean_per_launch"], ctrs["WRITE_SIZE"]["mean_per_launch"]
             head = f"rocprofv3 FETCH_SIZE {f:.0f} KiB + WRITE_SIZE {w:.0f} KiB per launch of {name.split('(')[0]}; "
@@ -92,20 +121,49 @@ def measured_traffic(workload, tris, stage):
     return None, None
 
 
+# cycles one SIMD needs per wave64 instruction, by class, with two or more waves resident: measured on
+# the GPU by profiles/tools/issue_rate.hip (profiles/r3_issue_rate.jsonl).  The classes are those of the
+# SQ_INSTS_VALU_* counters; "int32_simple" are the two-operand add / sub / shift / logic / compare /
+# select forms, "int32_other" everything else the INT32 counter takes (multiplies, three-operand and
+# SDWA forms), split by the static share of the kernel's disassembly (profiles/tools/valu_mix.py).
+VALU_CLASS_CYCLES = {"int32_simple": 2.35, "int32_other": 4.3, "int64": 4.4, "cvt": 4.3, "f64": 4.3, "trans_f32": 8.2,
+                     "trans_f64": 16.3, "f32_mul_add": 2.4, "f32_fma": 3.9, "other": 2.6}
+
+
 def valu_roofline(workload, tris, stage, kernel_ms):
-    """Second ceiling for the fill, which is bound by VALU issue: wave-instructions per launch
-    (SQ_INSTS_VALU of the committed counter pass) over the kernel's measured duration, against
-    1024 SIMDs issuing one wave-instruction per 4 cycles at the 2.4 GHz peak clock."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_c2small.json")
-    if workload != "c2-small" or tris != 1_000_000 or not os.path.exists(path) or kernel_ms <= 0:
-        return None
-    for name, ctrs in json.load(open(path)).items():
-        if STAGE_KERNEL.get(stage, "?") in name and "SQ_INSTS_VALU" in ctrs:
-            insts = ctrs["SQ_INSTS_VALU"]["mean_per_launch"]
-            peak = 1024 * 2.4e9 / 4 / 1e9
-            ach = insts / (kernel_ms * 1e-3) / 1e9
-            return {"bound": "valu", "kernel": stage, "achieved": round(ach, 1), "peak": round(peak, 1),
-                    "unit": "G wave-instructions/s", "frac": round(ach / peak, 4), "wave_instructions_per_launch": int(insts)}
+    """Second ceiling for the fill, which is bound by VALU issue: the cycles its wave-instructions need on
+    the 1024 SIMDs -- per-class instruction counts of the committed counter passes (SQ_INSTS_VALU_*) times
+    the per-class issue cost measured on this GPU model -- over the kernel's measured duration at the
+    2.4 GHz peak clock.  frac 1 would be a SIMD that issues a vector instruction in every free slot."""
+    pmc, why = load_pmc(workload, tris)
+    if pmc is None or kernel_ms <= 0:
+        return {"bound": "valu", "kernel": stage, "frac": None, "note": why} if why else None
+    for name, ctrs in pmc.items():
+        if name.startswith("_") or STAGE_KERNEL.get(stage, "?") not in name or "SQ_INSTS_VALU" not in ctrs:
+            continue
+        g = lambda k: ctrs.get(k, {}).get("mean_per_launch", 0.0)
+        insts = g("SQ_INSTS_VALU")
+        mix = pmc.get("_meta", {}).get("valu_mix", {}).get(stage, {})
+        simple_share = mix.get("int32_simple_share", 0.5)
+        i32 = g("SQ_INSTS_VALU_INT32")
+        classes = {"int32_simple": i32 * simple_share, "int32_other": i32 * (1 - simple_share), "int64": g("SQ_INSTS_VALU_INT64"),
+                   "cvt": g("SQ_INSTS_VALU_CVT"),
+                   "f64": g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_ADD_F64"),
+                   "trans_f32": g("SQ_INSTS_VALU_TRANS_F32"), "trans_f64": g("SQ_INSTS_VALU_TRANS_F64"),
+                   "f32_mul_add": g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_ADD_F32"), "f32_fma": g("SQ_INSTS_VALU_FMA_F32")}
+        classes["other"] = max(insts - sum(classes.values()), 0.0)
+        have_classes = i32 > 0
+        cycles = sum(classes[k] * VALU_CLASS_CYCLES[k] for k in classes) if have_classes else insts * 4.3
+        peak_cycles_per_s = 1024 * 2.4e9
+        ach = cycles / (kernel_ms * 1e-3)
+        return {"bound": "valu", "kernel": stage, "achieved": round(ach / 1e9, 1), "peak": round(peak_cycles_per_s / 1e9, 1),
+                "unit": "G SIMD issue cycles/s", "frac": round(ach / peak_cycles_per_s, 4),
+                "wave_instructions_per_launch": int(insts),
+                "cycles_per_wave_instruction": round(cycles / insts, 3) if insts else None,
+                "classes": {k: int(v) for k, v in classes.items()} if have_classes else None,
+                "note": "issue cycles = per-class SQ_INSTS_VALU_* counts x cycles per wave64 instruction measured by "
+                        "profiles/tools/issue_rate.hip with >= 2 waves a SIMD (most VALU forms take 4.3 cycles here, the simple "
+                        "two-operand integer forms 2.35, v_rcp_f32 8.2, v_rcp_f64 16.3)"}
     return None
 
 
@@ -337,6 +395,48 @@ def c4_side(ctx, torch, dist, rank, world, dev, d_verts, d_polys, d_pv, sc, fram
                         f"{sc.width}x{sc.height}, object angles (f, 2f, 3f) & 255, translation (0, 0, 2048), clear per frame)",
             "frames": total, "ms_per_frame_per_gpu": round(dt / len(mine) * 1e3, 4),
             "mtris_per_s": round(sc.n_polys * total / dt / 1e6, 3), "mfragments_per_s": round(frags / dt / 1e6, 3)}
+
+
+def many_objects_side(ctx, torch, dist, world, dev, sc, d_verts, d_polys, d_pv, per_object=250, frames=24):
+    """The headline frame as a world of small objects, the only way a program written against the reference's
+    API can draw it (M_render_polygon_object takes at most 256 polygons, Engine.h:432-433): one table of
+    objects (lt_submit_objects_dev), every object with a matrix of its own -- and, for comparison, the same
+    objects as one lt_submit_object_dev call each."""
+    from raytracing_amd import objects as O
+    n = sc.n_polys
+    nobj = (n + per_object - 1) // per_object
+    table = np.zeros((nobj, O.OBJECT_INTS), np.int32)
+    table[:, :12] = sc.matrix.reshape(1, 12)
+    table[:, 11] += (np.arange(nobj) % 17 - 8).astype(np.int32)          # every object its own depth offset
+    table[:, 12] = np.arange(nobj) * (3 * per_object)
+    table[:, 13] = np.minimum(3 * per_object, sc.verts.shape[0] - table[:, 12])
+    polyobj = (np.arange(n) // per_object).astype(np.int32)
+    pv = sc.polyverts.copy()
+    pv[:, 0] -= np.repeat(table[polyobj, 12], 4)                          # vertex indices count from the object's first vertex
+    d_table, d_polyobj, d_pv_rel = (torch.from_numpy(a).to(dev) for a in (table, polyobj, pv))
+
+    def submit(k):
+        ctx.clear(0)
+        ctx.submit_objects_dev(d_table, d_polyobj, d_verts, d_polys, d_pv_rel, sc.render_type, sc.log_focus, max_edges=3)
+
+    dt, frags, _, _ = side_frames(ctx, torch, dist, world, dev, submit, frames)
+    out = {"workload": f"many_objects: the {n} triangles as {nobj} objects of {per_object}, one table of objects per frame, a matrix per object",
+           "frames": frames, "ms_per_frame": round(dt / frames * 1e3, 4), "mtris_per_s": round(n * frames * world / dt / 1e6, 3),
+           "mfragments_per_s": round(frags / dt / 1e6, 3)}
+    # one batch per object: object i's slices of the same arrays
+    polys_rel = sc.polys.copy()
+    d_polys_host = torch.from_numpy(polys_rel).to(dev)
+    mats = [table[i, :12].copy() for i in range(nobj)]
+
+    def submit_each(k):
+        ctx.clear(0)
+        for i in range(nobj):
+            a, b = i * per_object, min((i + 1) * per_object, n)
+            ctx.submit_object_dev(d_verts[3 * a:3 * b], d_polys_host[a:b], d_pv_rel, sc.render_type, sc.log_focus, matrix=mats[i], max_edges=3)
+
+    dt2, _, _, _ = side_frames(ctx, torch, dist, world, dev, submit_each, 2, warm=1)
+    out["one_batch_per_object_ms_per_frame"] = round(dt2 / 2 * 1e3, 3)
+    return out
 
 
 def c3_side(torch, dist, dev, local_rank, tris, q2_tris, frames=24):
@@ -629,6 +729,7 @@ def main():
         side["large_class"] = large_class(ctx, torch, dev, args.tris)
     if headline and not args.no_side_lines:
         side["c4"] = c4_side(ctx, torch, dist, rank, world, dev, d_verts, d_polys, d_pv, sc)
+        side["many_objects"] = many_objects_side(ctx, torch, dist, world, dev, sc, d_verts, d_polys, d_pv)
 
     if rank == 0:
         total_tris = sc.n_polys * args.steps * (1 if bands else world)

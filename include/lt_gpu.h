@@ -317,6 +317,41 @@ int lt_submit_object_dev(lt_ctx *ctx, const int32_t m[12],
                          const int32_t *d_polyverts, int npv,
                          int render_type, int log_focus, int force_linear, int max_edges);
 
+/* A sequence of M_render_polygon_object calls (EngPoly.cpp:499-525) as ONE batch: the reference
+ * takes objects of fewer than 1024 vertices and at most 256 polygons (Engine.h:432-433, guard at
+ * EngPoly.cpp:507-508), so a world of a million triangles is thousands of calls, and a GPU batch
+ * per call would cost each its own chain of kernels.  Here the objects of one frame that share
+ * render type, log_focus and force_linear are laid end to end in the same arrays as for
+ * lt_submit_object and a table names, per object, the matrix that the host built for it
+ * (T_set_self_rotation + T_cancatinate_self_world) and its range of the vertex array:
+ *   objects int32[nobj][16]  lt_object: m[12], vert_base, vert_count, two reserved words (0)
+ *   polyobj int32[np]        the object of every polygon; ascending, so that draw order (which
+ *                            decides between equal depths, GraphicsPoly.cpp:357) is the order of
+ *                            the calls, then the order inside each object
+ *   polyverts                vertex indices count from the object's vert_base and must lie
+ *                            below its vert_count; polys[p].first indexes polyverts as a whole
+ * A polygon whose polyobj is outside the table, or whose object's range leaves the vertex array,
+ * is not drawn and is reported like a vertex index out of range (LT_ERR_OVERFLOW at lt_flush).
+ * render_type: LT_FLAT, LT_SHADED or LT_TEXTURED (wireframe objects go through
+ * lt_submit_object one by one).  The frame is the same, pixel for pixel, as after one
+ * lt_submit_object per object in table order.  Pointers are HOST memory. */
+typedef struct lt_object {
+    int32_t m[12];
+    int32_t vert_base, vert_count;
+    int32_t reserved[2];
+} lt_object;
+int lt_submit_objects(lt_ctx *ctx, const lt_object *objects, int nobj, const int32_t *polyobj,
+                      const int32_t *verts, int nv,
+                      const int32_t *polys, const int32_t *polyaux, int np,
+                      const int32_t *polyverts, int npv,
+                      int render_type, int log_focus, int force_linear, int max_edges);
+/* The same with every array, the table included, already in DEVICE memory (nothing is copied). */
+int lt_submit_objects_dev(lt_ctx *ctx, const lt_object *d_objects, int nobj, const int32_t *d_polyobj,
+                          const int32_t *d_verts, int nv,
+                          const int32_t *d_polys, const int32_t *d_polyaux, int np,
+                          const int32_t *d_polyverts, int npv,
+                          int render_type, int log_focus, int force_linear, int max_edges);
+
 /* lt_submit_object_dev for callers that cannot allocate device memory: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
  * reference.  Same arguments, same result in the frame and the counters (LT_WIRE excepted: not

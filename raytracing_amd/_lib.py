@@ -18,6 +18,7 @@ EXPORTS = [
     "lt_plane_normals_dev", "lt_plane_normals", "lt_submit_lines_dev", "lt_submit_lines",
     "lt_set_clip_window", "lt_shade_points_dev", "lt_shade_points",
     "lt_set_tile_width", "lt_submit_object_dev_noalloc", "lt_submit_screen_polys_prp", "lt_polygon_rows_dev",
+    "lt_submit_objects", "lt_submit_objects_dev",
 ]
 
 
@@ -75,6 +76,8 @@ def lib():
     L.lt_submit_object.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
     L.lt_submit_object_dev.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
     L.lt_submit_object_dev_noalloc.argtypes = L.lt_submit_object_dev.argtypes
+    L.lt_submit_objects.argtypes = [vp, vp, i32, vp, vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, i32]
+    L.lt_submit_objects_dev.argtypes = L.lt_submit_objects.argtypes
     L.lt_polygon_rows_dev.argtypes = [vp, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]
     L.lt_submit_screen_polys.argtypes = [vp, i32, vp, i32, vp, i32, i32]
     L.lt_submit_screen_polys_prp.argtypes = [vp, vp, i32, vp, vp, i32, i32, i32]

@@ -116,7 +116,7 @@ struct lt_ctx {
     hipStream_t own_gs = nullptr, own_gs2 = nullptr, own_rs = nullptr;    // internal streams (non-blocking)
     hipStream_t gs = nullptr, rs = nullptr;            // streams in use: own_* or `stream`
     hipEvent_t ev_fork = nullptr;
-    DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn, s_prp;      // staging for host-pointer calls
+    DevBuf s_verts, s_polys, s_aux, s_pv, s_normals, s_pn, s_prp, s_objects, s_polyobj;      // staging for host-pointer calls
     DevBuf line_winner, line_colours, s_lines;   // wireframe: per-pixel winning line, per-polygon colour, staged lines
     // textures
     int *tex_data[LT_MAX_TEXTURES] = {};
@@ -344,7 +344,8 @@ BatchPlan plan_batch(const lt_ctx *c, bool screen, int dim, int np, int max_edge
 int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_t gs, hipStream_t rs, hipEvent_t geom_done,
                 hipEvent_t raster_done, bool timing, bool screen, int dim, const int32_t *m, const int *d_verts, int nv,
                 const int *d_polys, const int *d_aux, int np, const int *d_pv, int npv, int render_type, int log_focus,
-                int force_linear, const int *d_prp_src = nullptr)
+                int force_linear, const int *d_prp_src = nullptr, const ObjectDesc *d_objects = nullptr, const int *d_polyobj = nullptr,
+                int nobj = 0)
 {
     const int na = dim - 2;
     const int emax = pl.emax;
@@ -367,6 +368,8 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
     if (m) for (int i = 0; i < 12; i++) sa.m[i] = m[i];
     sa.verts = d_verts; sa.polys = d_polys; sa.polyaux = d_aux; sa.polyverts = d_pv;
     sa.np = np; sa.nv = nv; sa.npv = npv;
+    sa.objects = d_objects; sa.polyobj = d_polyobj; sa.nobj = nobj;
+    if (d_objects) sa.use_matrix = 1;
     sa.render_type = render_type; sa.log_focus = log_focus; sa.force_linear = force_linear;
     sa.max_edges = pl.max_edges;
     // tile width of this batch
@@ -485,7 +488,7 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
 // One batch through a work set of the context (grown on demand).
 int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_verts, int nv, const int *d_polys, const int *d_aux,
               int np, const int *d_pv, int npv, int render_type, int log_focus, int force_linear, int max_edges,
-              const int *d_prp_src = nullptr)
+              const int *d_prp_src = nullptr, const ObjectDesc *d_objects = nullptr, const int *d_polyobj = nullptr, int nobj = 0)
 {
     const BatchPlan pl = plan_batch(c, screen, dim, np, max_edges, 1u << 20, d_prp_src != nullptr);
     int rc;
@@ -547,7 +550,8 @@ int run_batch(lt_ctx *c, bool screen, int dim, const int32_t *m, const int *d_ve
     wa.sq_desc = (int *)w.sq_desc.p; wa.sq_tuples = (int *)w.sq_tuples.p;
     if (pl.nbands) { wa.bcnt = (unsigned *)w.bcnt.p; wa.bplace = (unsigned *)w.bplace.p; wa.blist = (unsigned *)w.blist.p; }
     rc = issue_batch(c, wa, pl, gs, rs, c->pipelined ? w.geom_done : nullptr, c->pipelined ? w.raster_done : nullptr, true,
-                     screen, dim, m, d_verts, nv, d_polys, d_aux, np, d_pv, npv, render_type, log_focus, force_linear, d_prp_src);
+                     screen, dim, m, d_verts, nv, d_polys, d_aux, np, d_pv, npv, render_type, log_focus, force_linear, d_prp_src,
+                     d_objects, d_polyobj, nobj);
     if (rc) return rc;
     if (c->pipelined) w.in_use = true;
     c->last_set = set;
@@ -707,7 +711,7 @@ int lt_ctx_destroy(lt_ctx *c)
     if (c->own_rs) (void)hipStreamSynchronize(c->own_rs);
     if (c->alt_rs) (void)hipStreamSynchronize(c->alt_rs);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn, &c->s_prp,
+    DevBuf *bufs[] = {&c->s_verts, &c->s_polys, &c->s_aux, &c->s_pv, &c->s_normals, &c->s_pn, &c->s_prp, &c->s_objects, &c->s_polyobj,
                       &c->line_winner, &c->line_colours, &c->s_lines};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1212,6 +1216,57 @@ int lt_submit_object_dev(lt_ctx *c, const int32_t m[12], const int32_t *d_verts,
                      log_focus, force_linear, max_edges);
 }
 
+int lt_submit_objects_dev(lt_ctx *c, const lt_object *d_objects, int nobj, const int32_t *d_polyobj, const int32_t *d_verts, int nv,
+                          const int32_t *d_polys, const int32_t *d_polyaux, int np, const int32_t *d_polyverts, int npv,
+                          int render_type, int log_focus, int force_linear, int max_edges)
+{
+    if (!c) return LT_ERR_ARG;
+    static_assert(sizeof(lt_object) == sizeof(ObjectDesc) && sizeof(lt_object) == 64, "lt_object is sixteen ints");
+    int dim = 0, rc;
+    if (render_type == LT_WIRE) return fail(c, LT_ERR_ARG, "lt_submit_objects: LT_WIRE objects go through lt_submit_object one by one");
+    if ((rc = check_type(c, render_type, &dim))) return rc;
+    if (np < 0 || nv < 0 || npv < 0 || nobj < 0) return fail(c, LT_ERR_ARG, "lt_submit_objects: negative count");
+    if (np == 0) return LT_OK;
+    if (nobj == 0 || !d_objects || !d_polyobj || !d_verts || !d_polys || !d_polyverts) return fail(c, LT_ERR_ARG, "lt_submit_objects: NULL array or empty table");
+    if (((size_t)d_objects & 15) != 0) return fail(c, LT_ERR_ARG, "lt_submit_objects: the table must be 16-byte aligned");
+    if (render_type == LT_FLAT && !d_polyaux) return fail(c, LT_ERR_ARG, "lt_submit_objects: LT_FLAT needs polyaux (m_red, m_green, m_blue)");
+    if (log_focus < 0 || log_focus > 30) return fail(c, LT_ERR_ARG, "lt_submit_objects: log_focus %d outside 0..30", log_focus);
+    if (!c->frame_defined) return fail(c, LT_ERR_ARG, "draw before the first lt_clear: the frame is undefined");
+    if ((rc = use_device(c))) return rc;
+    return run_batch(c, false, dim, nullptr, d_verts, nv, d_polys, d_polyaux, np, d_polyverts, npv, render_type, log_focus,
+                     force_linear, max_edges, nullptr, (const ObjectDesc *)d_objects, d_polyobj, nobj);
+}
+
+int lt_submit_objects(lt_ctx *c, const lt_object *objects, int nobj, const int32_t *polyobj, const int32_t *verts, int nv,
+                      const int32_t *polys, const int32_t *polyaux, int np, const int32_t *polyverts, int npv,
+                      int render_type, int log_focus, int force_linear, int max_edges)
+{
+    if (!c) return LT_ERR_ARG;
+    if (np == 0) return LT_OK;
+    if (np < 0 || nv <= 0 || npv <= 0 || nobj <= 0 || !objects || !polyobj || !verts || !polys || !polyverts)
+        return fail(c, LT_ERR_ARG, "lt_submit_objects: bad argument");
+    int rc = use_device(c);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->gs));       // earlier batches' set-up has read the staging arrays
+    HIPCHK(c, hipStreamSynchronize(c->own_gs2));
+    if ((rc = ensure(c, c->s_objects, (size_t)nobj * sizeof(lt_object)))) return rc;
+    if ((rc = ensure(c, c->s_polyobj, (size_t)np * 4))) return rc;
+    if ((rc = ensure(c, c->s_verts, (size_t)nv * 16))) return rc;
+    if ((rc = ensure(c, c->s_polys, (size_t)np * 16))) return rc;
+    if ((rc = ensure(c, c->s_pv, (size_t)npv * 24))) return rc;
+    if (polyaux && (rc = ensure(c, c->s_aux, (size_t)np * 16))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->s_objects.p, objects, (size_t)nobj * sizeof(lt_object), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_polyobj.p, polyobj, (size_t)np * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_verts.p, verts, (size_t)nv * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_polys.p, polys, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->s_pv.p, polyverts, (size_t)npv * 24, hipMemcpyHostToDevice, c->stream));
+    if (polyaux) HIPCHK(c, hipMemcpyAsync(c->s_aux.p, polyaux, (size_t)np * 16, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return lt_submit_objects_dev(c, (const lt_object *)c->s_objects.p, nobj, (const int32_t *)c->s_polyobj.p, (const int *)c->s_verts.p, nv,
+                                 (const int *)c->s_polys.p, polyaux ? (const int *)c->s_aux.p : nullptr, np, (const int *)c->s_pv.p,
+                                 npv, render_type, log_focus, force_linear, max_edges);
+}
+
 int lt_submit_object_dev_noalloc(lt_ctx *c, const int32_t m[12], const int32_t *d_verts, int nv, const int32_t *d_polys,
                                  const int32_t *d_polyaux, int np, const int32_t *d_polyverts, int npv, int render_type,
                                  int log_focus, int force_linear, int max_edges)
@@ -1231,7 +1286,20 @@ int lt_submit_object_dev_noalloc(lt_ctx *c, const int32_t m[12], const int32_t *
     if (!dev.ptr) return fail(c, LT_ERR_HIP, "lt_submit_object_dev_noalloc: the static work array has no address on device %d", c->device);
 
     // carve the work arrays out of the static array, 256 bytes apart at least
-    const BatchPlan pl = plan_batch(c, false, dim, np, max_edges, 1u << 16);
+    // tile-list capacity: the same minimum as lt_submit_object_dev (2^20 entries, 4 MB), so that a
+    // batch of few but large polygons draws the same; only where that does not fit the array
+    // beside the batch's other arrays, the smaller minimum
+    BatchPlan pl = plan_batch(c, false, dim, np, max_edges, 1u << 20);
+    {
+        const BatchPlan small = plan_batch(c, false, dim, np, max_edges, 1u << 16);
+        auto total = [](const BatchPlan &q) {
+            const size_t parts[] = {q.flags, q.tcount, q.toffset, q.tcursor, q.hdr, q.edges, q.list, q.want_prp ? q.prp : 0, q.queue, q.sq_queue, q.sq_desc, q.sq_tuples};
+            size_t t = 0;
+            for (size_t b : parts) t += (b + 255) & ~(size_t)255;
+            return t;
+        };
+        if (total(pl) > (size_t)LT_NOALLOC_SCRATCH_BYTES && total(small) <= (size_t)LT_NOALLOC_SCRATCH_BYTES) pl = small;
+    }
     WorkArrays wa;
     size_t used = 0;
     unsigned char *base = (unsigned char *)dev.ptr;
@@ -1266,7 +1334,9 @@ int lt_submit_object_dev_noalloc(lt_ctx *c, const int32_t m[12], const int32_t *
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_fork, 0));
     }
     // the array is shared by every call on this GPU: wait for the batch that used it last
-    // (it may be on the other frame's stream, or another context's)
+    // (it may be on the other frame's stream, or another context's); from this wait to the
+    // record below no other host thread may enqueue a batch that uses the array
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
     if (dev.pending) HIPCHK(c, hipStreamWaitEvent(s, dev.done, 0));
     HIPCHK(c, hipMemsetAsync(base, 0, zeroed, s));              // order flag, sub-queue counters, tile counts
     rc = issue_batch(c, wa, pl, s, s, nullptr, nullptr, false, false, dim, m, d_verts, nv, d_polys, d_polyaux, np, d_polyverts,

@@ -72,9 +72,18 @@ struct Status {
     unsigned long long zero_light_vectors;   // shading: (vertex, point light) pairs at zero distance, skipped
 };
 
+// One object of a table of objects drawn by one batch (lt_submit_objects): its concatenated
+// transform (T_cancatinate_self_world, TransBs.cpp:325-361) and its range of the shared vertex
+// array; the vertex indices of its polygons' records count from vert_base.  Same layout as
+// lt_object in lt_gpu.h.
+struct ObjectDesc { int m[12]; int vert_base, vert_count, reserved0, reserved1; };
+
 struct SetupArgs {
     int m[12];               // concatenated transform, applied while vertices are read
     int use_matrix;          // 0: verts are already in view space
+    const ObjectDesc *objects;   // non-null: a table of objects; polyobj[p] names polygon p's object
+    const int *polyobj;
+    int nobj;
     const int *verts;        // int32[nv][4]                  (object mode)
     const int *polys;        // int32[np][4]                  (object mode) / desc (screen mode)
     const int *polyaux;      // int32[np][4] or null

@@ -303,6 +303,45 @@ __device__ __forceinline__ int4 load_vertex(const SetupArgs &a, int idx)
     return view_vertex(a, ((const int4 *)a.verts)[idx]);
 }
 
+// Where a polygon's vertices come from.  One object per batch: the whole vertex array and the
+// batch's matrix (kernel arguments).  A table of objects (MULTI): the polygon's object gives
+// the range of the shared vertex array that its records index and the matrix, which is read
+// from the table with every vertex (the general set-up kernels are short of registers; the
+// table is a few cache lines).
+template <bool MULTI>
+struct VertexSource {
+    int obj, vbase;
+    unsigned vcount;
+    // false: the polygon names no object of the table
+    __device__ __forceinline__ bool init(const SetupArgs &a, int poly)
+    {
+        obj = 0; vbase = 0; vcount = (unsigned)a.nv;
+        if (MULTI) {
+            obj = a.polyobj[poly];
+            if ((unsigned)obj >= (unsigned)a.nobj) { obj = 0; vcount = 0; return false; }
+            const int4 r = ((const int4 *)(a.objects + obj))[3];
+            vbase = r.x; vcount = (unsigned)r.y;
+            if (vbase < 0 || r.y < 0 || (long long)vbase + r.y > (long long)a.nv) { vcount = 0; return false; }
+        }
+        return true;
+    }
+    __device__ __forceinline__ bool valid(int idx) const { return (unsigned)idx < vcount; }
+    __device__ __forceinline__ int4 load(const SetupArgs &a, int idx) const
+    {
+        if (!MULTI) return load_vertex(a, idx);
+        int4 p = ((const int4 *)a.verts)[vbase + idx];
+        const int4 *m = (const int4 *)(a.objects + obj);
+        int o[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int4 row = m[r];
+            o[r] = wadd(wadd(wadd(wmul(row.x, p.x) >> 15, wmul(row.y, p.y) >> 15), wmul(row.z, p.z) >> 15), row.w);
+        }
+        p.x = o[0]; p.y = o[1]; p.z = o[2];
+        return p;
+    }
+};
+
 // ------------------------------------------------------------------ clipping
 
 template <int DIM>
@@ -503,7 +542,7 @@ __device__ __forceinline__ const int4 *record_header(const int *edges, int npiec
 // with p3 the stored closing tuple.  Everything else (other edge counts, near-plane or
 // screen-border contact, perspective-mapped textures) is appended to a queue for the
 // general kernel, which then runs only on those polygons with all its lanes busy.
-template <int DIM>
+template <int DIM, bool MULTI>
 __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArgs a)
 {
     // The kernels of a batch's set-up chain run beside the fills of earlier batches, each waiting
@@ -532,6 +571,25 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
         if (e != 3 || e > a.max_edges || first < 0 || (long long)first + 4 > (long long)a.npv ||
             (kind == KIND_TEX_LIN && tex >= 64))
             slow = true;
+        // a table of objects: this polygon's matrix and its range of the vertex array
+        int om[12];
+        int vbase = 0;
+        unsigned vcount = (unsigned)a.nv;
+        if (MULTI) {
+            const int o = a.polyobj[poly];
+            int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+            if ((unsigned)o < (unsigned)a.nobj) {
+                const int4 *od = (const int4 *)(a.objects + o);
+                r0 = od[0]; r1 = od[1]; r2 = od[2]; r3 = od[3];
+            } else {
+                slow = true;             // the general kernel reports it
+            }
+            om[0] = r0.x; om[1] = r0.y; om[2] = r0.z; om[3] = r0.w;
+            om[4] = r1.x; om[5] = r1.y; om[6] = r1.z; om[7] = r1.w;
+            om[8] = r2.x; om[9] = r2.y; om[10] = r2.z; om[11] = r2.w;
+            vbase = r3.x; vcount = (unsigned)r3.y;
+            if (vbase < 0 || r3.y < 0 || (long long)vbase + r3.y > (long long)a.nv) slow = true;
+        }
         int2 ra[4] = {}, rb[4] = {}, rc[4] = {};
         // A wave whose 64 triangles keep their vertex records one after the other
         // (first = first0 + 4*lane) reads the 6 KB block with consecutive 16-byte loads
@@ -569,8 +627,10 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
         }
         if (!slow) {
 #pragma unroll
-            for (int i = 0; i < 4; i++)
-                if ((unsigned)ra[i].x >= (unsigned)a.nv) slow = true;
+            for (int i = 0; i < 4; i++) {
+                if ((unsigned)ra[i].x >= vcount) slow = true;
+                ra[i].x += vbase;                 // index into the shared vertex array
+            }
         }
         // likewise the vertices of a triangle soup: indices v0 + 3*lane + {0, 1, 2, 0}
         const int v0 = rdlane(ra[0].x, 0);
@@ -594,7 +654,16 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
         if (!slow) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int4 p = view_vertex(a, pv[i]);
+                int4 p = pv[i];
+                if (MULTI) {
+                    int o3[3];
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+                        o3[r] = wadd(wadd(wadd(wmul(om[4 * r], p.x) >> 15, wmul(om[4 * r + 1], p.y) >> 15), wmul(om[4 * r + 2], p.z) >> 15), om[4 * r + 3]);
+                    p.x = o3[0]; p.y = o3[1]; p.z = o3[2];
+                } else {
+                    p = view_vertex(a, p);
+                }
                 t[i].v[0] = p.x; t[i].v[1] = p.y; t[i].v[2] = p.z;
                 if (DIM >= 6) { t[i].v[3] = wshl(ra[i].y, 16); t[i].v[4] = wshl(rb[i].x, 16); t[i].v[5] = wshl(rb[i].y, 16); }
                 if (DIM == 8) {
@@ -791,7 +860,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
 // entry points); polys[] then holds {first, length, colour, tex} descriptors.
 // `first_known` (screen mode, >= 0): the polygon's first tuple, where the caller can tell it
 // without the descriptor, so that descriptor and tuples are fetched together.
-template <int DIM, bool SCREEN>
+template <int DIM, bool SCREEN, bool MULTI = false>
 __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, const int slot, const int first_known = -1)
 {
     constexpr int NA = DIM - 2;
@@ -814,6 +883,8 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
     if (e < 2 || e + 1 > 16 || e > a.max_edges || first < 0 || (long long)first + e + 1 > (long long)a.npv) {
         bad = true; go = false;
     }
+    VertexSource<MULTI && !SCREEN> vs;
+    if (!SCREEN && !vs.init(a, poly)) { bad = true; go = false; }
     if (kind >= KIND_TEX_LIN && (tex < 0 || tex >= 64)) { unsupported = true; go = false; }
     if (SCREEN && kind == KIND_TEX_PRP && !a.prp_given) { unsupported = true; go = false; }
 
@@ -850,10 +921,10 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
 #pragma unroll
             for (int i = 0; i < PRE; i++)
                 if (i <= e) {
-                    if ((unsigned)ra[i].x >= (unsigned)a.nv) { bad = true; go = false; }
+                    if (!vs.valid(ra[i].x)) { bad = true; go = false; }
                     else {
                         // CI_construct_tuples, EngBase.cpp:58-137
-                        int4 p = load_vertex(a, ra[i].x);
+                        int4 p = vs.load(a, ra[i].x);
                         tin[i].v[0] = p.x; tin[i].v[1] = p.y; tin[i].v[2] = p.z;
                         if (DIM >= 6) { tin[i].v[3] = wshl(ra[i].y, 16); tin[i].v[4] = wshl(rb[i].x, 16); tin[i].v[5] = wshl(rb[i].y, 16); }
                         if (DIM == 8) {
@@ -880,8 +951,8 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
         } else {
             for (int i = 0; i <= e; i++) {
                 int idx = a.polyverts[(size_t)(first + i) * 6];
-                if ((unsigned)idx >= (unsigned)a.nv) { bad = true; go = false; break; }
-                int4 p = load_vertex(a, idx);
+                if (!vs.valid(idx)) { bad = true; go = false; break; }
+                int4 p = vs.load(a, idx);
                 mn[0] = min(mn[0], p.x); mx[0] = max(mx[0], p.x);
                 mn[1] = min(mn[1], p.y); mx[1] = max(mx[1], p.y);
                 mn[2] = min(mn[2], p.z); mx[2] = max(mx[2], p.z);
@@ -931,7 +1002,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
             } else {
                 // CI_construct_tuples, EngBase.cpp:58-137
                 const int *rec = a.polyverts + (size_t)(first + it) * 6;
-                int4 p = load_vertex(a, rec[0]);
+                int4 p = vs.load(a, rec[0]);
                 t.v[0] = p.x; t.v[1] = p.y; t.v[2] = p.z;
                 if (DIM >= 6) { t.v[3] = wshl(rec[1], 16); t.v[4] = wshl(rec[2], 16); t.v[5] = wshl(rec[3], 16); }
                 if (DIM == 8) {
@@ -1146,7 +1217,7 @@ __global__ void __launch_bounds__(SETUP_THREADS) setup_kernel(SetupArgs a)
 // whole path.  One launch instead of two: the second kernel is nearly always almost empty,
 // and an empty launch still costs its dispatch, several times over when the chip is busy
 // with the fill of the previous batch.
-template <int DIM>
+template <int DIM, bool MULTI>
 __device__ __forceinline__ void setup_queues(const SetupArgs &a)
 {
     __builtin_amdgcn_s_setprio(3);          // see setup_fast_kernel
@@ -1170,7 +1241,7 @@ __device__ __forceinline__ void setup_queues(const SetupArgs &a)
         const unsigned cnt = min(a.queue_count[y * QUEUE_COUNT_STRIDE], a.queue_cap);
         for (unsigned qi = blockIdx.x * blockDim.x + threadIdx.x; qi < cnt; qi += gridDim.x * blockDim.x) {
             const uint2 e = a.queue[(size_t)y * a.queue_cap + qi];
-            if (e.x < a.queue_index_limit && e.y < (unsigned)a.np) setup_one<DIM, false>(a, (int)e.x, (int)e.y);
+            if (e.x < a.queue_index_limit && e.y < (unsigned)a.np) setup_one<DIM, false, MULTI>(a, (int)e.x, (int)e.y);
         }
     }
 }
@@ -1181,9 +1252,14 @@ __device__ __forceinline__ void setup_queues(const SetupArgs &a)
 // 0.1201 ms per frame).  The textured size needs all 256: held to 168 it spills 257 and C3 at 4K
 // goes from 1.13 to 1.21 ms.
 template <int DIM> __global__ void setup_queues_kernel(SetupArgs a);
-template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_kernel<3>(SetupArgs a) { setup_queues<3>(a); }
-template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_kernel<6>(SetupArgs a) { setup_queues<6>(a); }
-template <> __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_kernel<8>(SetupArgs a) { setup_queues<8>(a); }
+template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_kernel<3>(SetupArgs a) { setup_queues<3, false>(a); }
+template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_kernel<6>(SetupArgs a) { setup_queues<6, false>(a); }
+template <> __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_kernel<8>(SetupArgs a) { setup_queues<8, false>(a); }
+// the same for a batch that draws a table of objects (the polygon's object gives matrix and vertex range)
+template <int DIM> __global__ void setup_queues_objects_kernel(SetupArgs a);
+template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_objects_kernel<3>(SetupArgs a) { setup_queues<3, true>(a); }
+template <> __global__ void __launch_bounds__(SETUP_THREADS) __attribute__((amdgpu_waves_per_eu(3))) setup_queues_objects_kernel<6>(SetupArgs a) { setup_queues<6, true>(a); }
+template <> __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_objects_kernel<8>(SetupArgs a) { setup_queues<8, true>(a); }
 
 // ------------------------------------------------------------------ binning
 
@@ -2961,10 +3037,19 @@ void launch_setup(hipStream_t s, int dim, bool screen, const SetupArgs &a)
     // screen border for the screen-mode kernel (projected tuples), everything else for the
     // general kernel
     dim3 gf((a.np + SETUP_FAST_THREADS - 1) / SETUP_FAST_THREADS), bf(SETUP_FAST_THREADS);
-    if (dim == 3) hipLaunchKernelGGL((setup_fast_kernel<3>), gf, bf, 0, s, a);
-    else if (dim == 6) hipLaunchKernelGGL((setup_fast_kernel<6>), gf, bf, 0, s, a);
-    else hipLaunchKernelGGL((setup_fast_kernel<8>), gf, bf, 0, s, a);
     g = dim3(std::min((a.queue_cap + SETUP_THREADS - 1) / SETUP_THREADS, 8u), 2 * QUEUES);
+    if (a.objects) {
+        if (dim == 3) hipLaunchKernelGGL((setup_fast_kernel<3, true>), gf, bf, 0, s, a);
+        else if (dim == 6) hipLaunchKernelGGL((setup_fast_kernel<6, true>), gf, bf, 0, s, a);
+        else hipLaunchKernelGGL((setup_fast_kernel<8, true>), gf, bf, 0, s, a);
+        if (dim == 3) hipLaunchKernelGGL((setup_queues_objects_kernel<3>), g, b, 0, s, a);
+        else if (dim == 6) hipLaunchKernelGGL((setup_queues_objects_kernel<6>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((setup_queues_objects_kernel<8>), g, b, 0, s, a);
+        return;
+    }
+    if (dim == 3) hipLaunchKernelGGL((setup_fast_kernel<3, false>), gf, bf, 0, s, a);
+    else if (dim == 6) hipLaunchKernelGGL((setup_fast_kernel<6, false>), gf, bf, 0, s, a);
+    else hipLaunchKernelGGL((setup_fast_kernel<8, false>), gf, bf, 0, s, a);
     if (dim == 3) hipLaunchKernelGGL((setup_queues_kernel<3>), g, b, 0, s, a);
     else if (dim == 6) hipLaunchKernelGGL((setup_queues_kernel<6>), g, b, 0, s, a);
     else hipLaunchKernelGGL((setup_queues_kernel<8>), g, b, 0, s, a);

@@ -237,6 +237,24 @@ class Context:
                                                       _dp(d_polyaux), d_polys.shape[0], _dp(d_polyverts),
                                                       d_polyverts.shape[0], render_type, log_focus, force_linear, max_edges))
 
+    def submit_objects(self, objects, polyobj, verts, polys, polyverts, render_type, log_focus, polyaux=None,
+                       force_linear=0, max_edges=0):
+        """a table of objects as one batch (host arrays): objects int32[nobj][16] = matrix (12), vert_base,
+        vert_count, 0, 0; polyobj int32[np] ascending; the other arrays as for submit_object, laid end to end"""
+        ob, po_ = _i32(objects).reshape(-1, 16), _i32(polyobj).reshape(-1)
+        v, po, pv = _i32(verts).reshape(-1, 4), _i32(polys).reshape(-1, 4), _i32(polyverts).reshape(-1, 6)
+        pa = None if polyaux is None else _i32(polyaux).reshape(-1, 4)
+        self._chk(self.L.lt_submit_objects(self.h_ctx, _p(ob), ob.shape[0], _p(po_), _p(v), v.shape[0], _p(po), _p(pa),
+                                           po.shape[0], _p(pv), pv.shape[0], render_type, log_focus, force_linear, max_edges))
+
+    def submit_objects_dev(self, d_objects, d_polyobj, d_verts, d_polys, d_polyverts, render_type, log_focus,
+                           d_polyaux=None, force_linear=0, max_edges=0):
+        """submit_objects with every array (torch int32 tensors) already on the device"""
+        self._chk(self.L.lt_submit_objects_dev(self.h_ctx, _dp(d_objects), d_objects.shape[0], _dp(d_polyobj), _dp(d_verts),
+                                               d_verts.shape[0], _dp(d_polys), _dp(d_polyaux), d_polys.shape[0],
+                                               _dp(d_polyverts), d_polyverts.shape[0], render_type, log_focus,
+                                               force_linear, max_edges))
+
     def submit_scene(self, sc: Scene):
         for h, (tex, lg) in enumerate(sc.textures):
             self.texture_upload(h, tex, lg)

@@ -36,7 +36,7 @@ int Ts[9], Tw[9], Tc[12];                            // self / world rotation, c
 int Cb[4] = {0, 0, 0, 0};                            // clip window
 
 // queued draws: consecutive calls of one kind form one batch
-enum QKind { Q_NONE, Q_SCREEN, Q_VIEW, Q_LINES };
+enum QKind { Q_NONE, Q_SCREEN, Q_VIEW, Q_LINES, Q_OBJECTS };
 QKind q_kind = Q_NONE;
 int q_type = 0;                                      // LT_FLAT / LT_SHADED / LT_TEXTURED
 int q_focus = 0, q_force = 0;
@@ -45,6 +45,11 @@ std::vector<int32_t> q_prp;                          // Q_SCREEN with the perspe
 constexpr int LT_TEXTURED_PRP = 9;                   // queue type of G_prp_textured_polygon (no C-ABI render type)
 std::vector<int32_t> q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
 std::vector<int32_t> q_lines;                        // Q_LINES: {x1 y1 z1 x2 y2 z2 lit-colour 0}
+// Q_OBJECTS: consecutive M_render_polygon_object calls of one render type, laid end to end in
+// q_verts / q_polys / q_aux / q_pv, with one lt_object per call (its matrix and vertex range)
+// and each polygon's object: one GPU batch for all of them (lt_submit_objects)
+std::vector<lt_object> q_objects;
+std::vector<int32_t> q_polyobj;
 int q_max_edges = 0;
 // Textures are the caller's memory, read by the reference at draw time (GraphicsPoly.cpp:486).
 // Here a texel array is uploaded once and known by its address; the first use of an address
@@ -145,6 +150,10 @@ void run_queue()
         chk(lt_submit_object(g_ctx, nullptr, q_verts.data(), (int)(q_verts.size() / 4), q_polys.data(), q_aux.data(),
                              (int)(q_polys.size() / 4), q_pv.data(), (int)(q_pv.size() / 6), q_type, q_focus, q_force,
                              q_max_edges));
+    } else if (q_kind == Q_OBJECTS && !q_polys.empty()) {
+        chk(lt_submit_objects(g_ctx, q_objects.data(), (int)q_objects.size(), q_polyobj.data(), q_verts.data(),
+                              (int)(q_verts.size() / 4), q_polys.data(), q_aux.data(), (int)(q_polys.size() / 4), q_pv.data(),
+                              (int)(q_pv.size() / 6), q_type, q_focus, q_force, q_max_edges));
     } else if (q_kind == Q_LINES && !q_lines.empty()) {
         chk(lt_submit_lines(g_ctx, q_lines.data(), (int)(q_lines.size() / 8)));
     } else {
@@ -157,12 +166,13 @@ void run_queue()
     q_lines.clear();
     q_prp.clear();
     q_tuples.clear(); q_desc.clear(); q_verts.clear(); q_polys.clear(); q_aux.clear(); q_pv.clear();
+    q_objects.clear(); q_polyobj.clear();
     q_max_edges = 0;
 }
 
 void open_queue(QKind kind, int type)
 {
-    if (q_kind != kind || q_type != type || ((kind == Q_VIEW || type == LT_TEXTURED_PRP) && (q_focus != M_camera_log_focus || q_force != M_force_linear_tmapping)))
+    if (q_kind != kind || q_type != type || ((kind == Q_VIEW || kind == Q_OBJECTS || type == LT_TEXTURED_PRP) && (q_focus != M_camera_log_focus || q_force != M_force_linear_tmapping)))
         run_queue();
     q_kind = kind; q_type = type; q_focus = M_camera_log_focus; q_force = M_force_linear_tmapping;
     g_host_frame_current = false;
@@ -1033,6 +1043,13 @@ void M_shade_polygon_object(struct M_polygon_object *object, int x, int y, int z
     }
 }
 
+// Objects are queued, not submitted: the reference's limits (fewer than 1024 vertices and at most
+// 256 polygons an object, Engine.h:432-433) make a world of many triangles a sequence of many
+// calls, and consecutive calls of one render type become one table of objects, one GPU batch
+// (lt_submit_objects) -- the frame is that of the calls in turn.  The object's arrays are copied
+// now (the caller may change them after the call returns, as the reference allows); the batch
+// goes out when the frame is observed or cleared, when a draw of another kind follows, or when
+// the render type, the focus or M_force_linear_tmapping change.
 void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int z, int alp, int bet, int gam)
 {
     need_ctx();
@@ -1040,8 +1057,6 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
         HW_error((char *)"(Engine) Can't handle this many vertices in polygons.");      // EngPoly.cpp:507-508
     if (object->m_order) HW_error((char *)"(Engine) BSP-ordered objects are not supported by the GPU path.\n");
     const int type = lt_type();
-    run_queue();
-    g_host_frame_current = false;
     T_set_self_rotation((unsigned char)alp, (unsigned char)bet, (unsigned char)gam);
     T_cancatinate_self_world(x + M_camera_x, y + M_camera_y, z + M_camera_z);
     if (g_track_stores) {
@@ -1052,14 +1067,45 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
         for (int i = 0; i < object->m_no_polygons; i++) track_view_polygon(object->m_polygons[i], tmp.data(), nullptr, nullptr, type);
         if (type == M_WIRE) return;
     }
-    std::vector<int32_t> polys, aux, pv;
-    int me = 0;
-    for (int i = 0; i < object->m_no_polygons; i++) {
-        flatten_polygon(object->m_polygons[i], 0, polys, aux, pv);
-        if (object->m_polygons[i]->m_no_edges > me) me = object->m_polygons[i]->m_no_edges;
+    if (type == M_WIRE) {
+        // wireframes read the depth buffer without writing it and are drawn object by object
+        run_queue();
+        g_host_frame_current = false;
+        std::vector<int32_t> polys, aux, pv;
+        int me = 0;
+        for (int i = 0; i < object->m_no_polygons; i++) {
+            flatten_polygon(object->m_polygons[i], 0, polys, aux, pv);
+            if (object->m_polygons[i]->m_no_edges > me) me = object->m_polygons[i]->m_no_edges;
+        }
+        chk(lt_submit_object(g_ctx, Tc, object->m_vertices, object->m_no_vertices, polys.data(), aux.data(),
+                             object->m_no_polygons, pv.data(), (int)(pv.size() / 6), type, M_camera_log_focus,
+                             M_force_linear_tmapping, me));
+        g_tex_epoch++;                               // a batch has gone out, as in run_queue
+        return;
     }
-    chk(lt_submit_object(g_ctx, Tc, object->m_vertices, object->m_no_vertices, polys.data(), aux.data(),
-                         object->m_no_polygons, pv.data(), (int)(pv.size() / 6), type, M_camera_log_focus,
-                         M_force_linear_tmapping, me));
-    g_tex_epoch++;                                   // a batch has gone out, as in run_queue
+    open_queue(Q_OBJECTS, type);
+    // Textures first, before anything of this object is queued: a new texture may have to submit the
+    // open batch to free a handle.  If that happened part-way, the textures seen before it carry the
+    // old batch's mark: look them all up once more (the open batch is empty now).
+    for (int pass = 0; pass < 2; pass++) {
+        const unsigned epoch = g_tex_epoch;
+        for (int i = 0; i < object->m_no_polygons; i++) {
+            const M_polygon *p = object->m_polygons[i];
+            if (p->m_texture) texture_handle(p->m_texture->m_texture_bytes, p->m_texture->m_log_texture_size, true);
+        }
+        if (g_tex_epoch == epoch) break;
+    }
+    open_queue(Q_OBJECTS, type);
+    lt_object o{};
+    for (int k = 0; k < 12; k++) o.m[k] = Tc[k];
+    o.vert_base = (int32_t)(q_verts.size() / 4);
+    o.vert_count = object->m_no_vertices;
+    const int index = (int)q_objects.size();
+    q_objects.push_back(o);
+    q_verts.insert(q_verts.end(), object->m_vertices, object->m_vertices + (size_t)object->m_no_vertices * T_LNG_VECTOR);
+    for (int i = 0; i < object->m_no_polygons; i++) {
+        flatten_polygon(object->m_polygons[i], 0, q_polys, q_aux, q_pv);
+        q_polyobj.push_back(index);
+        if (object->m_polygons[i]->m_no_edges > q_max_edges) q_max_edges = object->m_polygons[i]->m_no_edges;
+    }
 }

@@ -162,3 +162,47 @@ def test_more_texture_arrays_than_handles(eng):
                               *obj[3:], *obj[:3])
     c, z = _frame(eng)
     assert np.array_equal(z, orc.zbuf()) and np.array_equal(c, orc.cbuf())
+
+
+def test_many_objects_become_tables_and_the_frame_is_that_of_the_calls_in_turn(eng):
+    """M_render_polygon_object forty times over one frame -- runs of Gouraud, flat, textured and Gouraud objects, every
+    object with its own place and angles: the mirror turns each run into one table of objects (one GPU batch).
+    Against the reference build's own M_render_polygon_object, call by call, where oracle/_ref has it for this screen."""
+    import oracle.port as P
+    import oracle.ref as R
+    use_ref = os.path.exists(R.so_path(W, H))
+    chk = R.Ref(W, H) if use_ref else P.Oracle(W, H)
+    cam = (3, 251, 2, 12, -6, -30)
+    lf = 7
+    tex = np.ascontiguousarray(S.make_texture(77, 6), dtype=np.int32)
+    eng.lte_set_texture(0, _p(tex), 6)
+    chk.set_texture(0, tex, 6)
+    chk.clear(0x304050, 255, 250, 245)
+    eng.lte_clear(0x304050, 255, 250, 245)
+    if use_ref:
+        chk.make_matrix(cam, (0, 0, 0, 0, 0, 0), lf)       # M_set_camera
+    keep = []
+    runs = [(S.M_SHADED, 14), (S.M_FLAT, 9), (S.M_TEXTURED, 10), (S.M_SHADED, 7)]
+    k = 0
+    for (rt, n) in runs:
+        for _ in range(n):
+            if rt == S.M_TEXTURED:
+                # (regular texture mappings: on a singular one the reference divides by zero, TransBs.cpp:505)
+                sc = S.gen_c3(60 + k % 40, W, H, lf, radius=14, seed=5000 + k, equal_lights=True, lin_percent=70, regular_mapping=True)
+            else:
+                sc = S.gen_fuzz_polys(70 + k % 40, W, H, lf, 5000 + k, render_type=rt, max_edges=3 + k % 4)
+            assert sc.verts.shape[0] < 1024 and sc.polys.shape[0] <= 256
+            pos = (k % 5 - 2, 3 - k % 7, 20 + 9 * (k % 11))
+            ang = ((5 * k) % 256 if k % 4 == 0 else 0, (250 + k) % 256 if k % 3 == 0 else 0, k % 6)
+            v, po, pa, pv = sc.verts.copy(), sc.polys.copy(), sc.polyaux.copy(), sc.polyverts.copy()
+            keep.append((v, po, pa, pv))
+            if use_ref:
+                chk.render_object(v, po, pa, pv, rt, pos, ang)
+            else:
+                m = P.make_matrix(cam, ang + pos, 0)
+                chk.render_polys(P.transform(m, v), po, pa, pv, rt, lf)
+            eng.lte_render_object(_p(v), v.shape[0], _p(po), _p(pa), _p(pv), po.shape[0], rt, *cam, lf, *pos, *ang)
+            k += 1
+    c, z = _frame(eng)
+    assert np.array_equal(z, chk.zbuf()), f"depth differs at {int((z != chk.zbuf()).sum())} pixels"
+    assert np.array_equal(c, chk.cbuf()), f"colour differs at {int((c != chk.cbuf()).sum())} pixels"

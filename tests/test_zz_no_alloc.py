@@ -62,6 +62,21 @@ def test_two_calls_second_smaller_shaded():
     _same(_frames([big, small], True, 640, 480), _frames([big, small], False, 640, 480))
 
 
+def test_few_large_polygons_fill_the_tile_lists_alike():
+    """a few thousand polygons that each cover many tiles (about 100 000 tile references: more than the
+    smaller list minimum held); the flush code is part of the comparison, and so is the CPU checker's frame"""
+    import oracle.port as P
+    big = S.gen_c2(14000, 1920, 1080, 10, radius=220, seed=31)
+    small = S.gen_c2(300, 1920, 1080, 10, radius=200, seed=32)
+    a, b = _frames([big, small], True, 1920, 1080), _frames([big, small], False, 1920, 1080)
+    _same(a, b)
+    assert a[0][2]["flush_code"] == 0 and a[0][2]["tile_refs"] > (1 << 16)
+    orc = P.Oracle(1920, 1080)
+    orc.clear(0x102030, 255, 255, 255)
+    orc.render_polys(P.transform(big.matrix, big.verts), big.polys, None, big.polyverts, big.render_type, big.log_focus)
+    assert np.array_equal(a[0][1], orc.zbuf()) and np.array_equal(a[0][0], orc.cbuf())
+
+
 @pytest.mark.parametrize("rt", [S.M_FLAT, S.M_SHADED, S.M_TEXTURED])
 def test_clipped_polygons_all_kinds(rt):
     """polygons of 3..6 edges that meet the near plane and the screen borders, every fill;
