@@ -485,9 +485,18 @@ __device__ __forceinline__ const int4 *edge_piece(const int *edges, int np, int 
     return (const int4 *)edges + edge_unit(np, npieces, e, piece, poly);
 }
 
+// The deltas of an edge as every later stage wants them: |dx| | |dy| << 15 | (dx >= 0) << 30 |
+// (dy < 0) << 31 (coordinates are below 2^15: the screen is at most 16384 wide and high).
+__device__ __forceinline__ int edge_pack(int x1, int y1, int x2, int y2)
+{
+    const int dx = x2 - x1, dy = y2 - y1;
+    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+    return adx | (ady << 15) | (dx >= 0 ? 1 << 30 : 0) | (dy < 0 ? (int)0x80000000 : 0);
+}
+
 // Edge record of one scanned edge v1 -> v2 (after the y clip): GI_scan's set-up,
-// GraphicsPoly.cpp:147-176.  record = {x1|y1<<16, x2|y2<<16, Zstart, Zinc, other starts..,
-// other incs..} in 16-byte pieces, placed by edge_piece().
+// GraphicsPoly.cpp:147-176.  record = {x1|y1<<16, edge_pack(deltas), Zstart, Zinc, other starts..,
+// other incs..} in 16-byte pieces, placed by edge_piece().  (x2, y2 themselves are not kept: every reader wants the deltas.)
 template <int DIM>
 __device__ __forceinline__ void make_edge_record(const Tup<DIM> &v1, const Tup<DIM> &v2, int (&rec)[edge_ints(DIM - 2)])
 {
@@ -501,7 +510,7 @@ __device__ __forceinline__ void make_edge_record(const Tup<DIM> &v1, const Tup<D
 #pragma unroll
     for (int q = 0; q < ESZ; q++) rec[q] = 0;
     rec[0] = x1 | (y1 << 16);
-    rec[1] = x2 | (y2 << 16);
+    rec[1] = edge_pack(x1, y1, x2, y2);
     const double rL = drcp(L > 0 ? L : 1);
     rec[2] = wshl(v1.v[2], 16);
     rec[3] = L > 0 ? tdivr(wshl(wsub(v2.v[2], v1.v[2]), 16), rL) : 0;
@@ -1464,15 +1473,14 @@ __global__ void __launch_bounds__(1024) scan_kernel(unsigned *__restrict__ count
 //    edge keeps the row end.
 // edge_row() gives, for one edge and one row, the point index and x of the row's
 // leftmost and rightmost point on that edge; it returns false if the edge misses the row.
-__device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &xa, int &ib, int &xb)
+__device__ __forceinline__ bool edge_row(int xy1, int P, int y, int &ia, int &xa, int &ib, int &xb)
 {
     // Branch-free: both the y-major and the x-major forms divide by 2*|dy| (2L for a
     // y-major edge, 2s for an x-major one), so one reciprocal serves both quotients
-    // and selects pick the form that applies.
-    const int x1 = xy1 & 0xffff, y1 = (xy1 >> 16) & 0xffff, x2 = xy2 & 0xffff, y2 = (xy2 >> 16) & 0xffff;
-    const int dx = x2 - x1, dy = y2 - y1;
-    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-    const int j = dy < 0 ? y1 - y : y - y1;
+    // and selects pick the form that applies.  P: the edge's packed deltas (edge_pack).
+    const int x1 = xy1 & 0xffff, y1 = (int)((unsigned)xy1 >> 16);
+    const int adx = P & 0x7fff, ady = (P >> 15) & 0x7fff;
+    const int j = P < 0 ? y1 - y : y - y1;
     const bool hit = (unsigned)j <= (unsigned)ady;
     const bool xmaj = adx > ady;
     const int d2 = ady > 0 ? 2 * ady : 1;                       // a horizontal edge or a point uses no quotient
@@ -1487,7 +1495,7 @@ __device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &
     const int ihi = j == ady ? adx : qC - 1;
     const int ohi = xmaj ? ihi : olo;
     const int lo = xmaj ? olo : j, hi = xmaj ? ihi : j;         // point indices of the row's two end points
-    const bool fwd = dx >= 0;
+    const bool fwd = (P & (1 << 30)) != 0;
     ia = fwd ? lo : hi;
     ib = fwd ? hi : lo;
     xa = fwd ? x1 + olo : x1 - ohi;
@@ -1496,20 +1504,13 @@ __device__ __forceinline__ bool edge_row(int xy1, int xy2, int y, int &ia, int &
 }
 
 // The same closed form with everything that does not depend on the row made once per edge:
-//   P  = |dx| | |dy| << 15 | (dx >= 0) << 30 | (dy < 0) << 31     (edge_pack)
+//   P  = |dx| | |dy| << 15 | (dx >= 0) << 30 | (dy < 0) << 31     (edge_pack: the record's second word)
 //   hr = 0.5 / |dy| in double precision                          (1.0 for a horizontal edge)
 // Both quotients divide by 2*|dy|; floor(N / (2k)) = floor((N >> 1) / k) for N >= 0, and with
 // m = 2*(N >> 1) + 1 the product m * hr lies at least 1/(2k) away from every integer, far more
 // than its rounding error (m < 2^31, k < 2^15), so truncating it gives the quotient exactly:
 // one 24-bit multiply, two conversions each way and two f64 multiplies per (edge, row)
 // instead of a reciprocal and two corrected single-precision quotients.
-__device__ __forceinline__ int edge_pack(int xy1, int xy2)
-{
-    const int x1 = xy1 & 0xffff, y1 = (xy1 >> 16) & 0xffff, x2 = xy2 & 0xffff, y2 = (xy2 >> 16) & 0xffff;
-    const int dx = x2 - x1, dy = y2 - y1;
-    const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-    return adx | (ady << 15) | (dx >= 0 ? 1 << 30 : 0) | (dy < 0 ? (int)0x80000000 : 0);
-}
 __device__ __forceinline__ bool edge_row_pre(int xy1, int P, double hr, int y, int &ia, int &xa, int &ib, int &xb)
 {
     const int x1 = xy1 & 0xffff, y1 = (int)((unsigned)xy1 >> 16);
@@ -1557,6 +1558,17 @@ __device__ __forceinline__ double2 rcp_pair(const double2 *lut, int d)         /
     }
     return l;
 }
+// 0.5 / d alone (the divisor of an edge's point indices)
+__device__ __forceinline__ double rcp_half(const double2 *lut, int d)         // d >= 1
+{
+    double h = lut[d < 64 ? d : 63].y;
+    if (__ballot(d >= 64)) {
+        int big = d;
+        asm volatile("" : "+v"(big));        // see rcp_pair
+        if (big >= 64) h = 0.5 * drcp(big);
+    }
+    return h;
+}
 // trunc(n / d) given rcp_pair(d)
 __device__ __forceinline__ int tdivp(int n, const double2 rp) { return (int)fma((double)n, rp.x, n < 0 ? -rp.y : rp.y); }
 
@@ -1577,9 +1589,9 @@ __device__ __forceinline__ bool row_ends(const int *__restrict__ edges, int np, 
             int ia, xa, ib, xb;
             bool hit;
             if (lut) {
-                const int P = edge_pack(pre[e].x, pre[e].y);
+                const int P = pre[e].y;
                 const int ady = (P >> 15) & 0x7fff;
-                hit = edge_row_pre(pre[e].x, P, rcp_pair(lut, ady > 0 ? ady : 1).y, y, ia, xa, ib, xb);
+                hit = edge_row_pre(pre[e].x, P, rcp_half(lut, ady > 0 ? ady : 1), y, ia, xa, ib, xb);
             } else {
                 hit = edge_row(pre[e].x, pre[e].y, y, ia, xa, ib, xb);
             }
@@ -1691,7 +1703,7 @@ __device__ __forceinline__ long long depth_key(int z, unsigned id)
 // touches the row.  zs = depth accumulator at beg (16.16), zi = per-pixel increment
 // (GraphicsPoly.cpp:352-353; the flat fill skips the divide when end == beg, which
 // leaves the single pixel's depth unchanged: GraphicsPoly.cpp:273).
-struct Edge4 { int xy1, xy2, z0, zi; };
+struct Edge4 { int xy1, xy2, z0, zi; };      // xy2: the packed deltas (edge_pack)
 
 __device__ __forceinline__ bool depth_row3(const Edge4 (&ed)[3], int ne, int y, int &beg, int &end, int &zs, int &zi)
 {
@@ -2744,14 +2756,26 @@ __global__ void __launch_bounds__(TH * (TW / 8)) raster_kernel(RasterArgs a)
                 // what the rows of this polygon share is made here, once: the packed deltas and
                 // the reciprocal of each edge (an edge the polygon does not have gets a first
                 // row that no row of the screen equals)
-                int P[3];
+                int P[3], ady[3];
                 double hr[3];
 #pragma unroll
                 for (int e = 0; e < 3; e++) {
-                    P[e] = e < ne ? edge_pack(ed[e].xy1, ed[e].xy2) : 0;
-                    const int ady = (P[e] >> 15) & 0x7fff;
-                    hr[e] = rcp_pair(rlut, ady > 0 ? ady : 1).y;
+                    P[e] = e < ne ? ed[e].xy2 : 0;             // the record keeps the packed deltas
+                    ady[e] = (P[e] >> 15) & 0x7fff;
                     st[rank * 5 + e] = make_int4(e < ne ? ed[e].xy1 : (int)0xffff0000, P[e], ed[e].z0, ed[e].zi);
+                }
+                // the three table reads together, and one test for heights the table does not hold
+                // (a tile with a long list runs alone on its CU at the end, where every dependent
+                // LDS round trip of this step shows)
+#pragma unroll
+                for (int e = 0; e < 3; e++) hr[e] = rlut[ady[e] < 64 ? ady[e] : 63].y;
+                if (__ballot(max(ady[0], max(ady[1], ady[2])) >= 64)) {
+#pragma unroll
+                    for (int e = 0; e < 3; e++) {
+                        int big = ady[e];
+                        asm volatile("" : "+v"(big));        // see rcp_pair
+                        if (big >= 64) hr[e] = 0.5 * drcp(big);
+                    }
                 }
                 st[rank * 5 + 3] = make_int4(__double2loint(hr[0]), __double2hiint(hr[0]), __double2loint(hr[1]), __double2hiint(hr[1]));
                 st[rank * 5 + 4] = make_int4(__double2loint(hr[2]), __double2hiint(hr[2]), poly, ne | (r0 << 5) | ((incl - cnt) << 19));

@@ -16,7 +16,7 @@ and expected outputs -- stored as .npz (no pickles) and .json next to this scrip
   stale_depth_kats.json  frames with screen-clipped lines drawn after filled polygons (their end
                     points' depth is a leftover in the clippers' static stores)
   prp_kats.json     frames of G_prp_textured_polygon calls (the perspective mapper at the G_* level)
-  c4_frames.json    configuration 4: digests of four frames of the animated 1M-triangle batch
+  c4_frames.json    configuration 4: digests of thirty-two frames of the animated 1M-triangle batch
   c5_frame.json     configuration 5 in shape: digests of one 16384 x 16384 frame of 1M triangles
   data_kats.json    what the reference's D_data builds from the .dat files of
                     tests/test_data_loader.py and from tracer.dat
@@ -637,7 +637,8 @@ def prp_kats():
     return out
 
 
-C4_FRAMES = (1, 37, 100, 203)
+# the four frames of the first fixture and twenty-eight more spread over the 1024-frame batch
+C4_FRAMES = tuple(sorted(set((1, 37, 100, 203) + tuple(range(5, 1024, 37)))))
 
 
 def c4_frames():
@@ -681,6 +682,9 @@ def main():
         return
     if "--prp" in sys.argv:
         json.dump(prp_kats(), open(os.path.join(HERE, "prp_kats.json"), "w"), indent=1, sort_keys=True)
+        return
+    if "--c4" in sys.argv:
+        json.dump(c4_frames(), open(os.path.join(HERE, "c4_frames.json"), "w"), indent=1, sort_keys=True)
         return
     if "--c4c5" in sys.argv:
         json.dump(c4_frames(), open(os.path.join(HERE, "c4_frames.json"), "w"), indent=1, sort_keys=True)
