@@ -96,6 +96,11 @@ int lt_set_list_capacity(lt_ctx *ctx, uint64_t refs);
  * drawn between two lt_flush calls averaged 256 depth tests or more.  The frame does not
  * depend on it.  No counterpart in the reference. */
 int lt_set_tile_width(lt_ctx *ctx, int width);
+/* Waves that share one 64-pixel tile of the fill: 4 (the rule), 8, or 0 = chosen by the library from
+ * the tile lists of the batches before the last lt_flush (8 when polygons crowd into few tiles, e.g. an
+ * object drawn small: the fill lasts as long as the longest list, and more waves shorten that).  No
+ * counterpart in the reference; the frame and the counters do not depend on it. */
+int lt_set_tile_waves(lt_ctx *ctx, int waves);
 
 /* The reference's textured fills advance the light accumulators only where the depth
  * test passes (GraphicsPoly.cpp:485-493, 666-674), so with a light gradient along a span

@@ -18,7 +18,7 @@ EXPORTS = [
     "lt_plane_normals_dev", "lt_plane_normals", "lt_submit_lines_dev", "lt_submit_lines",
     "lt_set_clip_window", "lt_shade_points_dev", "lt_shade_points",
     "lt_set_tile_width", "lt_submit_object_dev_noalloc", "lt_submit_screen_polys_prp", "lt_polygon_rows_dev",
-    "lt_submit_objects", "lt_submit_objects_dev",
+    "lt_submit_objects", "lt_submit_objects_dev", "lt_set_tile_waves",
 ]
 
 
@@ -65,6 +65,7 @@ def lib():
     L.lt_submit_lines.argtypes = [vp, vp, i32]
     L.lt_set_clip_window.argtypes = [vp, i32, i32, i32, i32]
     L.lt_set_tile_width.argtypes = [vp, i32]
+    L.lt_set_tile_waves.argtypes = [vp, i32]
     L.lt_shade_points_dev.argtypes = [vp, vp, vp, vp, i32, vp, i32, vp]
     L.lt_shade_points.argtypes = L.lt_shade_points_dev.argtypes
     L.lt_set_pipelining.argtypes = [vp, i32]

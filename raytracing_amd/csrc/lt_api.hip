@@ -70,6 +70,10 @@ struct lt_ctx {
     bool auto_wide = false;                        // the choice when tile_mode == 0
     bool fragment_heavy = false;                   // the last look found >= 256 depth tests a polygon: batches are not overlapped
     unsigned long long seen_fragments = 0, seen_drawn = 0;
+    int tile_waves = 0;                            // 0: chosen from the last batches' longest tile lists; else 4 / 8 waves on a 64-pixel tile
+    bool auto_waves8 = false;                      // the choice when tile_waves == 0
+    unsigned long long seen_longest = 0, seen_refs = 0;
+    unsigned seen_batches = 0;
     hipStream_t stream = nullptr;
     int *cbuf = nullptr, *zbuf = nullptr;          // the frame being drawn (own or bound)
     int *own_cbuf = nullptr, *own_zbuf = nullptr;  // allocated by lt_ctx_create
@@ -241,14 +245,14 @@ int sync_all(lt_ctx *c)
 // sum of the device status slots; the stream must be idle
 int read_status(lt_ctx *c, Status *out)
 {
-    static_assert(sizeof(Status) == 8 * sizeof(unsigned long long), "Status is eight counters");
+    static_assert(sizeof(Status) == 9 * sizeof(unsigned long long), "Status is nine counters");
     std::vector<Status> slots(STATUS_SLOTS);
     HIPCHK(c, hipMemcpy(slots.data(), c->status, sizeof(Status) * STATUS_SLOTS, hipMemcpyDeviceToHost));
     unsigned long long *o = (unsigned long long *)out;
-    for (int k = 0; k < 8; k++) o[k] = 0;
+    for (int k = 0; k < 9; k++) o[k] = 0;
     for (const Status &s : slots) {
         const unsigned long long *v = (const unsigned long long *)&s;
-        for (int k = 0; k < 8; k++) o[k] += v[k];
+        for (int k = 0; k < 9; k++) o[k] += v[k];
     }
     return LT_OK;
 }
@@ -452,12 +456,13 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
     ra.status = c->status;
     // A Gouraud or flat fill that shares the chip with the set-up chains of other batches leaves
     // them room in LDS (not the textured fill: measured slower with it, 1.148 -> 1.159 ms at 4K)
-    const unsigned fill_lds = (geom_done && c->fill_shares_chip && tile_w == TW_NARROW && dim != 8) ? FILL_OVERLAP_LDS : 0u;
+    const int waves = tile_w == TW_NARROW && (c->tile_waves ? c->tile_waves == 8 : c->auto_waves8) ? 8 : 4;
+    const unsigned fill_lds = (geom_done && c->fill_shares_chip && tile_w == TW_NARROW && dim != 8 && waves == 4) ? FILL_OVERLAP_LDS : 0u;
     // The fill's events are its own dispatch's where no other kernel follows it: its start
     // and end for the stage timing, else its completion as this work set's "free" signal.
     if (ordered_follows) {
         if ((rc = stage_begin(c, 4, rs))) return rc;
-        launch_raster(rs, na, tile_w, ra, nullptr, nullptr, fill_lds);
+        launch_raster(rs, na, tile_w, ra, nullptr, nullptr, fill_lds, waves);
         // (the per-band lists on the fill's stream: made on the geometry stream, beside the fill of
         // the batch before, they slow that fill down by more than they take here)
         if (band_lists) HIPCHK(c, launch_band_lists(rs, np, c->device, ba));
@@ -469,10 +474,10 @@ int issue_batch(lt_ctx *c, const WorkArrays &wa, const BatchPlan &pl, hipStream_
         if ((rc = new_event(c, (hipStream_t)-1, &sp.begin))) return rc;
         if ((rc = new_event(c, (hipStream_t)-1, &sp.end))) return rc;
         c->spans.push_back(sp);
-        launch_raster(rs, na, tile_w, ra, c->ev_pool[sp.begin], c->ev_pool[sp.end], fill_lds);
+        launch_raster(rs, na, tile_w, ra, c->ev_pool[sp.begin], c->ev_pool[sp.end], fill_lds, waves);
         if (raster_done) HIPCHK(c, hipEventRecord(raster_done, rs));
     } else {
-        launch_raster(rs, na, tile_w, ra, nullptr, raster_done, fill_lds);
+        launch_raster(rs, na, tile_w, ra, nullptr, raster_done, fill_lds, waves);
     }
     HIPCHK(c, hipGetLastError());
     c->batch_no++;
@@ -776,6 +781,13 @@ int lt_set_tile_width(lt_ctx *c, int width)
     return LT_OK;
 }
 
+int lt_set_tile_waves(lt_ctx *c, int waves)
+{
+    if (!c || (waves != 0 && waves != 4 && waves != 8)) return fail(c, LT_ERR_ARG, "lt_set_tile_waves: 0, 4 or 8");
+    c->tile_waves = waves;
+    return LT_OK;
+}
+
 int lt_set_textured_order(lt_ctx *c, int mode)
 {
     const int lists = mode & (LT_ORDER_LISTS_ALWAYS | LT_ORDER_LISTS_NEVER);
@@ -891,6 +903,16 @@ int lt_flush(lt_ctx *c)
         c->fragment_heavy = c->auto_wide;
         c->seen_fragments = s.fragments; c->seen_drawn = s.polys_drawn;
     }
+    // Waves on a 64-pixel tile for the batches to come: eight once the longest tile list of the batches since
+    // the last look averaged 2048 entries or more and eight times the average list (polygons
+    // crowded into few tiles: the fill lasts as long as its longest list).
+    if (c->batch_no > c->seen_batches) {
+        const unsigned long long nb = c->batch_no - c->seen_batches;
+        const unsigned long long longest = (s.longest_lists - c->seen_longest) / nb;
+        const unsigned long long mean = (s.tile_refs - c->seen_refs) / nb / (unsigned long long)(c->ntiles > 0 ? c->ntiles : 1);
+        c->auto_waves8 = longest >= 2048 && longest >= 8 * (mean > 0 ? mean : 1);
+        c->seen_longest = s.longest_lists; c->seen_refs = s.tile_refs; c->seen_batches = c->batch_no;
+    }
     if (s.list_overflow > c->base.list_overflow) {
         c->base.list_overflow = s.list_overflow;
         return fail(c, LT_ERR_CAPACITY,
@@ -981,6 +1003,7 @@ int lt_reset_counters(lt_ctx *c)
     c->base = Status{};
     c->polys_in = 0;
     c->seen_fragments = 0; c->seen_drawn = 0;
+    c->seen_longest = 0; c->seen_refs = 0; c->seen_batches = c->batch_no;
     return LT_OK;
 }
 

@@ -70,6 +70,7 @@ struct Status {
     unsigned long long unsupported_polys;
     unsigned long long list_overflow;
     unsigned long long zero_light_vectors;   // shading: (vertex, point light) pairs at zero distance, skipped
+    unsigned long long longest_lists;        // sum over the batches of each batch's longest tile list
 };
 
 // One object of a table of objects drawn by one batch (lt_submit_objects): its concatenated
@@ -190,7 +191,7 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tile
                     unsigned *offset, unsigned *cursor, unsigned *list, unsigned long long capacity,
                     unsigned *queue_count, Status *status, hipEvent_t after_scan, bool counted, hipEvent_t done,
                     const int *order_flag = nullptr, int order_gen = 0, int order_force = 0);
-void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop, unsigned extra_lds = 0);
+void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a, hipEvent_t start, hipEvent_t stop, unsigned extra_lds = 0, int waves = 4);
 hipError_t launch_ordered(hipStream_t s, const RasterArgs &a, int device, const BandArgs *bands);   // textured batches only; `device` is current
 void launch_fill(hipStream_t s, int *cbuf, int *zbuf, size_t n, int colour);
 

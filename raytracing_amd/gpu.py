@@ -179,6 +179,10 @@ class Context:
         """64, 128, or 0 = chosen by the library"""
         self._chk(self.L.lt_set_tile_width(self.h_ctx, int(width)))
 
+    def set_tile_waves(self, waves):
+        """waves on a 64-pixel tile of the fill: 4, 8, or 0 = chosen by the library"""
+        self._chk(self.L.lt_set_tile_waves(self.h_ctx, waves))
+
     def set_clip_window(self, minx, miny, maxx, maxy):
         """C_init_clipping for the batches submitted next"""
         self._chk(self.L.lt_set_clip_window(self.h_ctx, int(minx), int(miny), int(maxx), int(maxy)))

@@ -34,14 +34,16 @@ SCENES = {
 }
 
 
-@pytest.mark.parametrize("width", [64, 128])
+@pytest.mark.parametrize("width,waves", [(64, 4), (64, 8), (128, 0)])
 @pytest.mark.parametrize("name", sorted(SCENES))
-def test_frame_is_independent_of_tile_width(env, name, width):
+def test_frame_is_independent_of_tile_width(env, name, width, waves):
+    """... and of the number of waves that share a 64-pixel tile (lt_set_tile_waves)"""
     P, G = env
     sc = SCENES[name]()
     oc, oz, ok = oracle_frame(P, sc)
     ctx = G.Context(sc.width, sc.height)
     ctx.set_tile_width(width)
+    ctx.set_tile_waves(waves)
     ctx.clear(P.cl_light(0x102030, 255, 255, 255))
     ctx.submit_scene(sc)
     c, z = ctx.readback()
@@ -65,3 +67,24 @@ def test_library_switches_and_frames_stay_equal(env):
         ctx.submit_scene(sc)
         c, z = ctx.readback()                                    # flushes: the next batch may use the other width
         assert np.array_equal(c, oc) and np.array_equal(z, oz)
+
+
+def test_crowded_tiles_switch_the_library_to_eight_waves_and_frames_stay_equal(env):
+    """an object drawn small puts most of its polygons into a few tiles (lists of thousands where the average is tens):
+    after the next flush the library puts eight waves on a tile; evenly spread polygons take it back to four"""
+    P, G = env
+    from raytracing_amd import frames as F
+    far = S.gen_c2(150000, 1920, 1080, 10, radius=8, seed=8)
+    far.matrix = F.frame_matrix(0, translation=(0, 0, 9000))        # the soup at five times its distance: a fifth of its size
+    even = S.gen_c2(30000, 1920, 1080, 10, radius=8, seed=9)
+    ctx = G.Context(1920, 1080)
+    with pytest.raises(G.LtError):
+        ctx.set_tile_waves(6)
+    for sc in (far, far, even, even, far):
+        oc, oz, ok = oracle_frame(P, sc)
+        ctx.clear(P.cl_light(0x102030, 255, 255, 255))
+        ctx.reset_counters()
+        ctx.submit_scene(sc)
+        c, z = ctx.readback()
+        assert np.array_equal(c, oc) and np.array_equal(z, oz)
+        assert ctx.counters()["fragments"] == ok["fragments"]
