@@ -357,20 +357,22 @@ int lt_submit_objects_dev(lt_ctx *ctx, const lt_object *d_objects, int nobj, con
                           const int32_t *d_polyverts, int npv,
                           int render_type, int log_focus, int force_linear, int max_edges);
 
-/* lt_submit_object_dev for callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the
- * reference.  Same arguments, same result in the frame and the counters (LT_WIRE excepted: not
+/* lt_submit_object_dev for callers that must not allocate device memory while they draw: tight
+ * serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  (The call is
+ * not itself capturable into a HIP graph: it issues on the library's own streams and queries the
+ * caller's.)  Same arguments, same result in the frame and the counters (LT_WIRE excepted: not
  * supported here), but the batch's work arrays (polygon headers, edge records, tile lists,
  * set-up queues) are pieces of one static device array of LT_NOALLOC_SCRATCH_BYTES that each
  * GPU holds from the first lt_ctx_create on it until the process ends; the call makes no
- * hipMalloc / hipFree and uses no work set of the context.  A batch that needs more returns
- * LT_ERR_CAPACITY with the sizes in the message and draws nothing: about 60 000 Gouraud
- * triangles per call at max_edges = 3 (roughly 1000 bytes each with the set-up queues), fewer with more edges, a larger
- * lt_set_list_capacity or a textured batch.  All kernels run on the stream of the current
- * frame's fills, in submit order with every other submit of the context; stage timing
- * (lt_set_profiling) skips these batches.  Every call on a GPU shares that GPU's array: calls
- * of one host thread are ordered one after the other by the library (other contexts on the same
- * GPU included); calls issued from several host threads at once on one GPU race. */
+ * hipMalloc / hipFree and uses no work set of the context.  The tile lists get the same room as
+ * in lt_submit_object_dev (2^20 entries at least) unless only a smaller list lets the batch fit.
+ * A batch that needs more than the array returns LT_ERR_CAPACITY with the sizes in the message and
+ * draws nothing: about 55 000 Gouraud triangles per call at max_edges = 3 (roughly 1000 bytes
+ * each with the set-up queues), fewer with more edges, a larger lt_set_list_capacity or a textured
+ * batch.  All kernels run on the stream of the current frame's fills, in submit order with every
+ * other submit of the context; stage timing (lt_set_profiling) skips these batches.  Every call
+ * on a GPU shares that GPU's array: the library orders them one after the other, other contexts
+ * and other host threads on the same GPU included (the enqueueing of a call is done under a lock). */
 #define LT_NOALLOC_SCRATCH_BYTES (64u << 20)
 int lt_submit_object_dev_noalloc(lt_ctx *ctx, const int32_t m[12],
                                  const int32_t *d_verts, int nv,

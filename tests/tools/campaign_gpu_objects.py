@@ -1,5 +1,5 @@
 """Campaign, not collected by pytest: `python tests/tools/campaign_gpu_objects.py N` renders N fuzz objects (all render
-types, clip windows, both tile widths, draw-order modes, with and without pipelining) through the C-ABI and compares
+types, clip windows, both tile widths, four and eight waves a tile, draw-order modes, with and without pipelining) through the C-ABI and compares
 frames and counters with the CPU restatement.  Last run: 5000 cases, 0 differing."""
 import os, sys, time, numpy as np
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP starts: two frames in flight by default
@@ -8,7 +8,7 @@ import torch
 import oracle.port as P
 from raytracing_amd import scenes as S, gpu as G
 
-def check(sc, name, order=None, window=None, tile=0, pipel=True):
+def check(sc, name, order=None, window=None, tile=0, pipel=True, waves=0):
     W, H = sc.width, sc.height
     orc = P.Oracle(W, H)
     for h, (tex, lg) in enumerate(sc.textures):
@@ -25,6 +25,7 @@ def check(sc, name, order=None, window=None, tile=0, pipel=True):
         ctx.set_clip_window(*window)
     if tile:
         ctx.set_tile_width(tile)
+    ctx.set_tile_waves(waves)
     if not pipel:
         ctx.set_pipelining(False)
     ctx.clear(P.cl_light(0x102030, 255, 255, 255))
@@ -62,6 +63,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 400):
     if tex:
         kw["order"] = (0, 1, 1 | 4, 0 | 4)[it % 4]
     kw["tile"] = (0, 64, 128)[it % 3]
+    kw["waves"] = (0, 4, 8)[(it // 3) % 3]
     kw["pipel"] = it % 11 != 0
     total += 1
     if not check(sc, f"it {it} seed {seed} {W}x{H} rt {rt} n {n} me {me} {kw}", **kw):
