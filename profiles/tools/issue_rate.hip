@@ -14,10 +14,11 @@
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum { OP_ADD, OP_MAD24, OP_MULLO, OP_FMA64, OP_RCP32, OP_CVT, OP_FMA32, OP_CNDMASK, OP_ASHR, OP_DSMIN64, OP_DSREAD128, OP_MULHI, OP_LSHL64, OP_BFE, OP_ADD3, OP_MIN3, OP_MIX, OP_CND64, OP_CMP64, OP_SDWA, OP_ADDC, OP_MAD64, OP_LSHLADD64, OP_CVTF64, OP_RCP64, OP_CVTI64, OP_MULF64, OP_MULI24, OP_MULF32, OP_CVTIF32, OP_MAXI32, OP_MBCNT, OP_LSHLADD, OP_ANDOR, OP_READLANE, OP_SALU, OP_COUNT };
+enum { OP_ADD, OP_MAD24, OP_MULLO, OP_FMA64, OP_RCP32, OP_CVT, OP_FMA32, OP_CNDMASK, OP_ASHR, OP_DSMIN64, OP_DSREAD128, OP_MULHI, OP_LSHL64, OP_BFE, OP_ADD3, OP_MIN3, OP_MIX, OP_CND64, OP_CMP64, OP_SDWA, OP_ADDC, OP_MAD64, OP_LSHLADD64, OP_CVTF64, OP_RCP64, OP_CVTI64, OP_MULF64, OP_MULI24, OP_MULF32, OP_CVTIF32, OP_MAXI32, OP_MBCNT, OP_LSHLADD, OP_ANDOR, OP_READLANE, OP_SALU, OP_SEL4_VCC, OP_SEL4_E64, OP_SEL4_VCC_AND, OP_ANDLIT, OP_CMP32, OP_P1, OP_P2, OP_P3, OP_P4, OP_P5, OP_P6, OP_COUNT };
 static const char *names[] = {"v_add_u32", "v_mad_u32_u24", "v_mul_lo_u32", "v_fma_f64", "v_rcp_f32", "v_cvt_f32_i32", "v_fma_f32",
                               "v_cndmask_b32", "v_ashrrev_i32", "ds_min_i64", "ds_read_b128", "v_mul_hi_u32", "v_lshlrev_b64",
-                              "v_bfe_u32", "v_add3_u32", "v_min3_i32", "mix add/cndmask/cmp", "v_cndmask_b32_e64 (sgpr mask)", "v_cmp_lt_i32_e64 (sgpr dst)", "v_sub_u32_sdwa", "v_addc_co_u32_e64", "v_mad_u64_u32", "v_lshl_add_u64", "v_cvt_f64_i32", "v_rcp_f64", "v_cvt_i32_f64", "v_mul_f64", "v_mul_i32_i24", "v_mul_f32", "v_cvt_i32_f32", "v_max_i32", "v_mbcnt_lo+hi", "v_lshl_add_u32", "v_and_or_b32", "v_readlane_b32", "s_add_u32 x4"};
+                              "v_bfe_u32", "v_add3_u32", "v_min3_i32", "mix add/cndmask/cmp", "v_cndmask_b32_e64 (sgpr mask)", "v_cmp_lt_i32_e64 (sgpr dst)", "v_sub_u32_sdwa", "v_addc_co_u32_e64", "v_mad_u64_u32", "v_lshl_add_u64", "v_cvt_f64_i32", "v_rcp_f64", "v_cvt_i32_f64", "v_mul_f64", "v_mul_i32_i24", "v_mul_f32", "v_cvt_i32_f32", "v_max_i32", "v_mbcnt_lo+hi", "v_lshl_add_u32", "v_and_or_b32", "v_readlane_b32", "s_add_u32 x4",
+                              "cmp_e32 + 4 cndmask_e32 on vcc", "cmp_e64 + 4 cndmask_e64 on sgprs", "cmp_e32 + s_and vcc + 4 cndmask_e32", "v_and_b32 with a 32-bit literal", "v_cmp_lt_i32_e32 (vcc)", "cmp_e32; cndmask_e32", "cmp_e32; s_nop 1; cndmask_e32", "cmp_e32; add; add; cndmask_e32", "cndmask_e64 with vcc as mask", "s_mov vcc; s_nop 1; cndmask_e32", "cmp_e32; s_nop 1; cndmask_e32 x2"};
 
 template <int OP>
 __global__ void __launch_bounds__(256) rate_kernel(unsigned long long *stamps, int iters, int seed)
@@ -85,6 +86,26 @@ __global__ void __launch_bounds__(256) rate_kernel(unsigned long long *stamps, i
                 if (OP == OP_ANDOR) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(b));
                 if (OP == OP_READLANE) asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(ss[i & 3]) : "v"(a[i]));
                 if (OP == OP_SALU) asm volatile("s_add_u32 %0, %0, 3" : "+s"(ss[i & 3]));
+                if (OP == OP_SEL4_VCC && (i & 3) == 0)
+                    asm volatile("v_cmp_lt_i32_e32 vcc, %0, %4\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\t"
+                                 "v_cndmask_b32_e32 %2, %2, %4, vcc\n\tv_cndmask_b32_e32 %3, %3, %4, vcc"
+                                 : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(b) : "vcc");
+                if (OP == OP_SEL4_E64 && (i & 3) == 0)
+                    asm volatile("v_cmp_lt_i32_e64 %5, %0, %4\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %4, %5\n\tv_cndmask_b32_e64 %1, %1, %4, %5\n\t"
+                                 "v_cndmask_b32_e64 %2, %2, %4, %5\n\tv_cndmask_b32_e64 %3, %3, %4, %5"
+                                 : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(b), "s"(sm[(i >> 2) & 3]));
+                if (OP == OP_SEL4_VCC_AND && (i & 3) == 0)
+                    asm volatile("v_cmp_lt_i32_e32 vcc, %0, %4\n\ts_and_b64 vcc, vcc, %5\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\t"
+                                 "v_cndmask_b32_e32 %2, %2, %4, vcc\n\tv_cndmask_b32_e32 %3, %3, %4, vcc"
+                                 : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]) : "v"(b), "s"(smask) : "vcc");
+                if (OP == OP_ANDLIT) asm volatile("v_and_b32_e32 %0, 0x12345, %0" : "+v"(a[i]));
+                if (OP == OP_CMP32) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+                if (OP == OP_P1) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (OP == OP_P2) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %1\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (OP == OP_P3) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %2\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %1, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc" : "+v"(a[i]), "+v"(a[(i + 5) & 15]) : "v"(b) : "vcc");
+                if (OP == OP_P4) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+                if (OP == OP_P5) asm volatile("s_mov_b64 vcc, %2\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b), "s"(smask) : "vcc");
+                if (OP == OP_P6) asm volatile("v_cmp_lt_i32_e32 vcc, %0, %2\n\ts_nop 1\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(a[i]), "+v"(a[(i + 5) & 15]) : "v"(b) : "vcc");
                 if (OP == OP_MIX) {
                     asm volatile("v_add_u32 %0, %0, %1\n\tv_cmp_lt_i32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc\n\tv_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b) : "vcc");
                 }
@@ -112,7 +133,7 @@ template <int OP>
 static void run(int wps, int iters, int ncu, unsigned long long *dev, std::vector<unsigned long long> &host)
 {
     const int blocks = ncu * wps;
-    const int per_inst = OP == OP_MIX ? 4 : 1;
+    const double per_inst = OP == OP_MIX ? 4 : (OP == OP_SEL4_VCC || OP == OP_SEL4_E64 || OP == OP_SEL4_VCC_AND) ? 1.25 : (OP == OP_P1 || OP == OP_P2) ? 2 : OP == OP_P3 ? 4 : OP == OP_P6 ? 3 : 1;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(256), 0, 0, dev, 10, 1);       // warm-up
@@ -155,6 +176,19 @@ int main(int argc, char **argv)
     const size_t n = 1 + (size_t)ncu * 4 * 8;
     CHECK(hipMalloc(&dev, n * 8));
     std::vector<unsigned long long> host(n);
+    sweep<OP_SEL4_VCC>(iters, ncu, dev, host);
+    sweep<OP_SEL4_E64>(iters, ncu, dev, host);
+    sweep<OP_SEL4_VCC_AND>(iters, ncu, dev, host);
+    sweep<OP_ANDLIT>(iters, ncu, dev, host);
+    sweep<OP_CMP32>(iters, ncu, dev, host);
+    sweep<OP_CNDMASK>(iters, ncu, dev, host);
+    sweep<OP_P1>(iters, ncu, dev, host);
+    sweep<OP_P2>(iters, ncu, dev, host);
+    sweep<OP_P3>(iters, ncu, dev, host);
+    sweep<OP_P4>(iters, ncu, dev, host);
+    sweep<OP_P5>(iters, ncu, dev, host);
+    sweep<OP_P6>(iters, ncu, dev, host);
+    if (argc > 2) { CHECK(hipFree(dev)); return 0; }       // a second argument: the select-group cases only
     sweep<OP_ADD>(iters, ncu, dev, host);
     sweep<OP_MAD24>(iters, ncu, dev, host);
     sweep<OP_MULLO>(iters, ncu, dev, host);

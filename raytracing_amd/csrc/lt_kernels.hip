@@ -660,10 +660,17 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
 #pragma unroll
             for (int i = 0; i < 4; i++) pv[i] = ((const int4 *)a.verts)[ra[i].x];
         }
+        // The fourth tuple of a triangle closes it: as a rule it names the first vertex again.  Where it
+        // does so in every lane of the wave, its position -- view space, then projected -- is the first
+        // tuple's and is not worked out a second time (a quarter of the kernel's divisions).
+        const bool closes = __ballot(!slow && ra[3].x != ra[0].x) == 0ull;
         if (!slow) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 int4 p = pv[i];
+                if (i == 3 && closes) {
+                    p.x = t[0].v[0]; p.y = t[0].v[1]; p.z = t[0].v[2];
+                } else
                 if (MULTI) {
                     int o3[3];
 #pragma unroll
@@ -705,6 +712,10 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
             bool inside = true, left = true, right = true, above = true, below = true;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
+                if (i == 3 && closes) {         // the first tuple's projection; the tests below have seen it
+                    t[3].v[0] = t[0].v[0]; t[3].v[1] = t[0].v[1]; t[3].v[2] = t[0].v[2];
+                    continue;
+                }
                 const int z = t[i].v[2];
                 const double rz = drcp(z);
                 t[i].v[0] = wadd(persp_div(t[i].v[0], a.log_focus, z, rz), xc);
@@ -2887,6 +2898,89 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
     // trip for the group, a second one for the winning edges' values).
     unsigned long long qrows = 0;
     constexpr int CG = 4;
+    if (NA == 4) {
+        // Gouraud fill: a winner's row is evaluated once for each run of neighbouring pixels that it
+        // won, not once per pixel (on one million small triangles at 1080p a run is 2.5 pixels on
+        // average, and the row's ends, owners and increments cost ten times what a pixel's colour
+        // costs once they are known).  The wave takes four runs of 64 pixels at a time.  The first pixel
+        // of every run of equal winners -- its leader -- is numbered through ballots; the leaders'
+        // winners go to a list in the wave's staging rows; 64 leaders at a time, one per lane, are
+        // evaluated into a table {colour, first pixel, light at the first pixel, light increments}; and
+        // every pixel whose leader is in the table takes its colour from there.
+        int4 *res = stage + (size_t)(t & ~63) * 5;            // 64 leaders x 2 pieces
+        unsigned *lead = (unsigned *)(res + 128);               // up to 256 leaders
+        for (int p0 = t; p0 < TW * TH; p0 += RASTER_THREADS * CG) {
+            long long kk[CG];
+            unsigned id[CG];
+            int off[CG + 1], pl[CG];
+            off[0] = 0;
+#pragma unroll
+            for (int g = 0; g < CG; g++) {
+                const int p = p0 + g * RASTER_THREADS;
+                const int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
+                const bool on = p < TW * TH && gx < a.W && gy < a.H;
+                kk[g] = on ? keys[ly * KW + lx] : 0ll;
+                id[g] = (unsigned)kk[g];
+                if (on && id[g] == 0u && a.clear_pending) {
+                    const size_t gi = (size_t)gy * a.W + gx;
+                    a.zbuf[gi] = INT_MAX; a.cbuf[gi] = a.clear_colour;
+                }
+                const unsigned left = (unsigned)__shfl_up((int)id[g], 1);
+                const bool leads = id[g] != 0u && (lane == 0 || left != id[g]);
+                const unsigned long long m = __ballot(leads);
+                const int mine = off[g] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                if (leads) lead[mine] = id[g];
+                // the leader of this pixel's run: the last one at or before this lane
+                pl[g] = mine - (leads ? 0 : 1);
+                off[g + 1] = off[g] + __popcll(m);
+            }
+            const int total = off[CG];
+            LDS_WAVE_SYNC();
+            for (int base = 0; base < total; base += 64) {
+                const int i = base + lane;
+                if (i < total) {
+                    const int g = (i >= off[1] ? 1 : 0) + (i >= off[2] ? 1 : 0) + (i >= off[3] ? 1 : 0);
+                    const int gy = ty0 + (p0 + g * RASTER_THREADS) / TW;       // the same for every lane of the wave
+                    const int poly = (int)(lead[i] - 1u);
+                    const int4 h = *record_header(a.edges, ESZ / 4, poly);
+                    int2 xy[3];
+#pragma unroll
+                    for (int e = 0; e < 3; e++) xy[e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
+                    const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff;
+                    int4 r0 = make_int4(h.z, 1 << 16, 0, 0), r1 = make_int4(0, 0, 0, 0);      // bit 16 of the second word: the colour as it is (flat)
+                    if (kind != KIND_FLAT) {
+                        int S[NA], E[NA], beg = 0, end = 0;
+                        row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E, xy, rlut);
+                        int span = end - beg;
+                        if (span == 0) span = 1;
+                        const double2 rs = rcp_pair(rlut, span);
+                        r0 = make_int4(h.z, beg, S[1], S[2]);
+                        r1 = make_int4(S[3], tdivp(wsub(E[1], S[1]), rs), tdivp(wsub(E[2], S[2]), rs), tdivp(wsub(E[3], S[3]), rs));
+                    }
+                    res[lane * 2] = r0;
+                    res[lane * 2 + 1] = r1;
+                }
+                LDS_WAVE_SYNC();
+#pragma unroll
+                for (int g = 0; g < CG; g++) {
+                    const int j = pl[g] - base;
+                    if (id[g] != 0u && (unsigned)j < 64u) {
+                        const int p = p0 + g * RASTER_THREADS;
+                        const int gx = tx0 + p % TW, gy = ty0 + p / TW;
+                        const int4 r0 = res[j * 2], r1 = res[j * 2 + 1];
+                        const int kl = gx - (r0.y & 0xffff);
+                        int c = r0.x;
+                        if (!(r0.y >> 16))
+                            c = cl_light(c, wadd(r0.z, wmul(kl, r1.y)) >> 16, wadd(r0.w, wmul(kl, r1.z)) >> 16, wadd(r1.x, wmul(kl, r1.w)) >> 16);
+                        const size_t gi = (size_t)gy * a.W + gx;
+                        a.zbuf[gi] = (int)(kk[g] >> 32);
+                        a.cbuf[gi] = c;
+                    }
+                }
+                LDS_WAVE_SYNC();        // the table is rewritten by the next 64 leaders, the list by the next four runs
+            }
+        }
+    } else
     for (int p0 = t; p0 < TW * TH; p0 += RASTER_THREADS * CG) {
         long long kk[CG];
         int4 hh[CG];
