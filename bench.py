@@ -68,7 +68,7 @@ def make_scene(workload, tris):
     raise SystemExit(f"unknown workload {workload}")
 
 
-STAGE_KERNEL = {"fill": "raster_kernel<4, 64>", "setup": "setup_fast_kernel", "bin": "scatter_kernel", "scan": "count_kernel"}
+STAGE_KERNEL = {"fill": "raster_kernel<4, 64", "setup": "setup_fast_kernel", "bin": "scatter_kernel", "scan": "count_kernel"}
 PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_c2small.json")
 KERNEL_SOURCES = ["lt_kernels.hip", "lt_api.hip", "lt_kernels.h", "lt_math.h"]
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static instruction mix of the tile fill: compiles raytracing_amd/csrc/lt_kernels.hip to gfx950 assembly
-(needs hipcc; no GPU) and counts, over the hot blocks of raster_kernel<4, 64> -- the triangle row step of
+(needs hipcc; no GPU) and counts, over the hot blocks of raster_kernel<4, 64, 256> -- the triangle row step of
 the depth pass and the colour pass -- which share of the integer instructions are the simple two-operand
 forms that a SIMD issues in about two cycles (add, sub, shifts, and / or / xor, compares to vcc, select
 on vcc) as against about four for everything else (profiles/tools/issue_rate.hip measures both).  The
@@ -48,7 +48,7 @@ def main():
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
                                os.path.join(CSRC, "lt_kernels.hip"), "-o", s], stderr=subprocess.DEVNULL)
         asm = open(s).read()
-    lines = kernel_asm(asm, "_ZN2lt13raster_kernelILi4ELi64EEEvNS_10RasterArgsE")
+    lines = kernel_asm(asm, "_ZN2lt13raster_kernelILi4ELi64ELi256EEEvNS_10RasterArgsE")
     ops = [l.split()[0] for l in lines if re.match(r"^\s+v_", l)]
     integer = [o for o in ops if not re.search(r"_f(16|32|64)|cvt|rcp|mfma|mov_b64", o)]
     simple = [o for o in integer if SIMPLE.match(o)]
