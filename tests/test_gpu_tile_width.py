@@ -88,3 +88,47 @@ def test_crowded_tiles_switch_the_library_to_eight_waves_and_frames_stay_equal(e
         c, z = ctx.readback()
         assert np.array_equal(c, oc) and np.array_equal(z, oz)
         assert ctx.counters()["fragments"] == ok["fragments"]
+
+
+def depth_tie_scene(n, width, height, log_focus, radius, seed):
+    """large triangles of constant depth, a few depths only: polygons that lie wholly behind what their tile
+    holds, many of them exactly as deep as it (between equal depths the earlier polygon stays)"""
+    sc = S.gen_c2(n, width, height, log_focus, radius=radius, seed=seed)
+    v = sc.verts.astype(np.int64)
+    for p in range(sc.n_polys):
+        first = int(sc.polys[p, 3])
+        idx = sc.polyverts[first:first + 3, 0]
+        znew = max(256, int(v[idx[0], 2]) // 512 * 512)
+        for i in idx:
+            zold = int(v[i, 2])
+            v[i, 0] = v[i, 0] * znew // zold
+            v[i, 1] = v[i, 1] * znew // zold
+            v[i, 2] = znew
+    sc.verts = v.astype(np.int32)
+    return sc
+
+
+@pytest.mark.parametrize("width", [64, 128])
+def test_polygons_behind_what_their_tile_holds(env, width):
+    """tile lists of thousands of large polygons (the coarse depth tests are on, and with the wide tile the class
+    of polygons that lie wholly behind their tile): frame, depth and the count of depth tests against the CPU
+    restatement, drawn once onto a cleared frame and once more onto the frame as it then is"""
+    P, G = env
+    for sc in (depth_tie_scene(20000, 512, 256, 9, 100, 21), S.gen_c2(20000, 512, 256, 9, radius=100, seed=22)):
+        o = P.Oracle(sc.width, sc.height)
+        o.clear(0x102030, 255, 255, 255)
+        o.reset_counters()
+        ctx = G.Context(sc.width, sc.height)
+        ctx.set_tile_width(width)
+        ctx.clear(P.cl_light(0x102030, 255, 255, 255))
+        ctx.reset_counters()
+        for again in range(2):
+            o.render_polys(P.transform(sc.matrix, sc.verts), sc.polys, sc.polyaux, sc.polyverts, sc.render_type, sc.log_focus, sc.force_linear)
+            ctx.submit_scene(sc)
+            c, z = ctx.readback()
+            assert np.array_equal(z, o.zbuf()) and np.array_equal(c, o.cbuf())
+            k = ctx.counters()
+            assert k["fragments"] == o.counters()["fragments"] and k["polys_drawn"] == o.counters()["polys_drawn"]
+            if width == 128:
+                assert k["tile_refs"] >= (again + 1) * 1024 * (sc.width // width) * (sc.height // 32)      # long lists: the coarse tests are on
+        ctx.close()
