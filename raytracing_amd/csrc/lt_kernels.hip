@@ -368,29 +368,38 @@ __device__ __forceinline__ bool clip_line(const Tup<DIM> &v1, const Tup<DIM> &v2
     } else {
         if (hi.v[AX] <= bmin) return false;
     }
+    // The reference keeps the interval's two ends l, r and its midpoint m; a step replaces the end on m's
+    // side by m (l if m is below the bound, `whereto`, else r) and halves again.  The end that stays is
+    // other = whereto ? r : l, the new midpoint is (m + other) >> 1 whichever end that was, and the end
+    // that stays in the step after is `other` again if the search goes the same way twice, else the old
+    // midpoint: one select a dimension and step instead of two, the same values in the same order.
     if (lo.v[AX] <= bmin) {
-        Tup<DIM> m = lo, r = hi, l = lo;
+        Tup<DIM> m = lo, other = hi;
         bool whereto = true;
         int guard = 0;
         while (m.v[AX] != bmin) {
-            l = sel(whereto, m, l);
-            r = sel(whereto, r, m);
-            midpoint(m, l, r);
-            whereto = m.v[AX] < bmin;
+            Tup<DIM> next;
+            midpoint(next, m, other);
+            const bool w2 = next.v[AX] < bmin;
+            other = sel(w2 == whereto, other, m);
+            m = next;
+            whereto = w2;
             if (++guard > 40) { bad = true; break; }
         }
         lo = m;
         moved = !swap;
     }
     if (BOTH && hi.v[AX] >= bmax) {
-        Tup<DIM> l = lo, m = hi, r = hi;
+        Tup<DIM> m = hi, other = lo;
         bool whereto = false;
         int guard = 0;
         while (m.v[AX] != bmax) {
-            l = sel(whereto, m, l);
-            r = sel(whereto, r, m);
-            midpoint(m, l, r);
-            whereto = m.v[AX] < bmax;
+            Tup<DIM> next;
+            midpoint(next, m, other);
+            const bool w2 = next.v[AX] < bmax;
+            other = sel(w2 == whereto, other, m);
+            m = next;
+            whereto = w2;
             if (++guard > 40) { bad = true; break; }
         }
         hi = m;
