@@ -1297,9 +1297,11 @@ template <> __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_obj
 // keeps its own per-tile histogram in LDS, so the chip-wide atomics shrink from one per
 // reference to one per (chunk, touched tile).  The order of a list's entries does not
 // matter: the fill resolves by (depth, draw index).
+// PER polygons a thread: 8 (chunks of 4096), and 16 for batches of four million polygons and more, where a
+// workgroup's flush of its histogram -- one chip-wide add per touched tile -- is what the kernels last
+// (ten million triangles at 4K: 1.07 -> 1.05 ms per frame; one million at 1080p lose 2 % that way).
 constexpr int BIN_THREADS = 512;
-constexpr int BIN_PER_THREAD = 8;
-constexpr int BIN_CHUNK = BIN_THREADS * BIN_PER_THREAD;
+constexpr int BIN_LARGE_BATCH = 1 << 22;
 
 __device__ __forceinline__ bool prim_tiles(const int4 h, int twl, int &tx0, int &tx1, int &ty0, int &ty1)
 {
@@ -1312,6 +1314,7 @@ __device__ __forceinline__ bool prim_tiles(const int4 h, int twl, int &tx0, int 
 // (`order_flag` non-null: a textured batch.  If its set-up has found that it must be filled in
 // draw order -- or the caller has asked for that, `order_force` -- the tile lists have no reader:
 // the tile fill returns at once and the draw-order kernels work from the headers.)
+template <int BIN_PER_THREAD>
 __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
                                                             int ntiles, unsigned *__restrict__ count,
                                                             const int *__restrict__ order_flag, int order_gen, int order_force)
@@ -1321,6 +1324,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
     if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
     __syncthreads();
+    constexpr int BIN_CHUNK = BIN_THREADS * BIN_PER_THREAD;
     const int base = blockIdx.x * BIN_CHUNK;
 #pragma unroll
     for (int k = 0; k < BIN_PER_THREAD; k++) {
@@ -1337,6 +1341,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
         if (hist[i]) atomicAdd(&count[i], hist[i]);
 }
 
+template <int BIN_PER_THREAD>
 __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__restrict__ hdr, int np, int twl, int tiles_x,
                                                               int ntiles, const unsigned *__restrict__ offset,
                                                               unsigned *__restrict__ cursor, unsigned *__restrict__ list,
@@ -1348,6 +1353,7 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__r
     if (order_flag && (order_force || *order_flag == order_gen)) return;
     for (int i = threadIdx.x; i < ntiles; i += BIN_THREADS) hist[i] = 0;
     __syncthreads();
+    constexpr int BIN_CHUNK = BIN_THREADS * BIN_PER_THREAD;
     const int base = blockIdx.x * BIN_CHUNK;
     int4 hs[BIN_PER_THREAD];
 #pragma unroll
@@ -2986,17 +2992,20 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
     // trip for the group, a second one for the winning edges' values).
     unsigned long long qrows = 0;
     constexpr int CG = 4;
-    if (NA == 4) {
-        // Gouraud fill: a winner's row is evaluated once for each run of neighbouring pixels that it
-        // won, not once per pixel (on one million small triangles at 1080p a run is 2.5 pixels on
-        // average, and the row's ends, owners and increments cost ten times what a pixel's colour
-        // costs once they are known).  The wave takes four runs of 64 pixels at a time.  The first pixel
-        // of every run of equal winners -- its leader -- is numbered through ballots; the leaders'
-        // winners go to a list in the wave's staging rows; 64 leaders at a time, one per lane, are
-        // evaluated into a table {colour, first pixel, light at the first pixel, light increments}; and
-        // every pixel whose leader is in the table takes its colour from there.
-        int4 *res = stage + (size_t)(t & ~63) * 5;            // 64 leaders x 2 pieces
-        unsigned *lead = (unsigned *)(res + 128);               // up to 256 leaders
+    if (NA >= 4) {
+        // Gouraud and textured fills: a winner's row is evaluated once for each run of neighbouring
+        // pixels that it won, not once per pixel (on one million small triangles at 1080p a run is 2.5
+        // pixels on average, on ten million textured ones at 4K 5.9, and the row's ends, owners and
+        // increments cost ten times what a pixel's colour costs once they are known).  The wave takes
+        // four runs of 64 pixels at a time.  The first pixel of every run of equal winners -- its leader
+        // -- is numbered through ballots; the leaders' winners go to a list in the wave's staging rows;
+        // 64 leaders at a time, one per lane, are evaluated into a table (Gouraud: {colour, first pixel,
+        // light at the first pixel, light increments}; textured: header words, polygon, both ends, light
+        // and texture coordinates at the first pixel and their increments); and every pixel whose leader
+        // is in the table takes its colour from there.
+        constexpr int RP = NA == 4 ? 2 : 4;                     // 16-byte pieces of a table entry
+        int4 *res = stage + (size_t)(t & ~63) * 5;            // 64 leaders x RP pieces
+        unsigned *lead = (unsigned *)(res + 64 * RP);           // up to 256 leaders (the wave's staging rows hold 320 pieces)
         for (int p0 = t; p0 < TW * TH; p0 += RASTER_THREADS * CG) {
             long long kk[CG];
             unsigned id[CG];
@@ -3035,18 +3044,27 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
 #pragma unroll
                     for (int e = 0; e < 3; e++) xy[e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
                     const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff;
-                    int4 r0 = make_int4(h.z, 1 << 16, 0, 0), r1 = make_int4(0, 0, 0, 0);      // bit 16 of the second word: the colour as it is (flat)
+                    int S[NA], E[NA], I[NA], beg = 0, end = 0;
+#pragma unroll
+                    for (int q = 0; q < NA; q++) { S[q] = 0; I[q] = 0; }
                     if (kind != KIND_FLAT) {
-                        int S[NA], E[NA], beg = 0, end = 0;
                         row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E, xy, rlut);
                         int span = end - beg;
                         if (span == 0) span = 1;
                         const double2 rs = rcp_pair(rlut, span);
-                        r0 = make_int4(h.z, beg, S[1], S[2]);
-                        r1 = make_int4(S[3], tdivp(wsub(E[1], S[1]), rs), tdivp(wsub(E[2], S[2]), rs), tdivp(wsub(E[3], S[3]), rs));
+#pragma unroll
+                        for (int q = 1; q < NA; q++) I[q] = tdivp(wsub(E[q], S[q]), rs);
                     }
-                    res[lane * 2] = r0;
-                    res[lane * 2 + 1] = r1;
+                    if (NA == 4) {
+                        // bit 16 of the second word: the colour as it is (flat)
+                        res[lane * RP] = make_int4(h.z, kind != KIND_FLAT ? beg : 1 << 16, S[1 % NA], S[2 % NA]);
+                        res[lane * RP + 1] = make_int4(S[3 % NA], I[1 % NA], I[2 % NA], I[3 % NA]);
+                    } else {
+                        res[lane * RP] = make_int4(h.z, h.w, poly, beg);
+                        res[lane * RP + 1] = make_int4(end, S[1 % NA], S[2 % NA], S[3 % NA]);
+                        res[lane * RP + 2 % RP] = make_int4(S[4 % NA], S[5 % NA], I[1 % NA], I[2 % NA]);
+                        res[lane * RP + 3 % RP] = make_int4(I[3 % NA], I[4 % NA], I[5 % NA], 0);
+                    }
                 }
                 LDS_WAVE_SYNC();
 #pragma unroll
@@ -3055,11 +3073,24 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
                     if (id[g] != 0u && (unsigned)j < 64u) {
                         const int p = p0 + g * RASTER_THREADS;
                         const int gx = tx0 + p % TW, gy = ty0 + p / TW;
-                        const int4 r0 = res[j * 2], r1 = res[j * 2 + 1];
-                        const int kl = gx - (r0.y & 0xffff);
+                        const int4 r0 = res[j * RP], r1 = res[j * RP + 1];
                         int c = r0.x;
-                        if (!(r0.y >> 16))
-                            c = cl_light(c, wadd(r0.z, wmul(kl, r1.y)) >> 16, wadd(r0.w, wmul(kl, r1.z)) >> 16, wadd(r1.x, wmul(kl, r1.w)) >> 16);
+                        if (NA == 4) {
+                            const int kl = gx - (r0.y & 0xffff);
+                            if (!(r0.y >> 16))
+                                c = cl_light(c, wadd(r0.z, wmul(kl, r1.y)) >> 16, wadd(r0.w, wmul(kl, r1.z)) >> 16, wadd(r1.x, wmul(kl, r1.w)) >> 16);
+                        } else {
+                            const int4 r2 = res[j * RP + 2 % RP], r3 = res[j * RP + 3 % RP];
+                            const int kind = (r0.y >> 8) & 0xff;
+                            if (kind != KIND_FLAT) {
+                                int S[NA], I[NA];
+                                S[0] = 0; I[0] = 0;
+                                S[1 % NA] = r1.y; S[2 % NA] = r1.z; S[3 % NA] = r1.w; S[4 % NA] = r2.x; S[5 % NA] = r2.y;
+                                I[1 % NA] = r2.z; I[2 % NA] = r2.w; I[3 % NA] = r3.x; I[4 % NA] = r3.y; I[5 % NA] = r3.z;
+                                if (kind >= KIND_TEX_LIN && ((r2.z | r2.w | r3.x) != 0)) qrows++;
+                                c = pixel_colour<NA>(a, make_int4(0, 0, r0.x, r0.y), r0.z, gx, gy, r0.w, r1.x, S, I, gx - r0.w);
+                            }
+                        }
                         const size_t gi = (size_t)gy * a.W + gx;
                         a.zbuf[gi] = (int)(kk[g] >> 32);
                         a.cbuf[gi] = c;
@@ -3285,14 +3316,16 @@ void launch_binning(hipStream_t s, const PrimHdr *hdr, int np, int twl, int tile
 {
     const bool lds = ntiles <= BIN_MAX_TILES;
     if (np > 0 && !counted) {
-        if (lds) hipLaunchKernelGGL(count_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, hdr, np, twl, tiles_x, ntiles, count, order_flag, order_gen, order_force);
+        if (lds && np >= BIN_LARGE_BATCH) hipLaunchKernelGGL((count_kernel<16>), dim3((np + BIN_THREADS * 16 - 1) / (BIN_THREADS * 16)), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, hdr, np, twl, tiles_x, ntiles, count, order_flag, order_gen, order_force);
+        else if (lds) hipLaunchKernelGGL((count_kernel<8>), dim3((np + BIN_THREADS * 8 - 1) / (BIN_THREADS * 8)), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, hdr, np, twl, tiles_x, ntiles, count, order_flag, order_gen, order_force);
         else hipLaunchKernelGGL(count_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, hdr, np, twl, tiles_x, count);
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, count, offset, cursor, ntiles, capacity, queue_count, status);
     if (after_scan) (void)hipEventRecord(after_scan, s);
     if (np > 0) {
         // `done` (may be null) is the scatter's own completion (see launch_raster)
-        if (lds) hipExtLaunchKernelGGL(scatter_kernel, dim3((np + BIN_CHUNK - 1) / BIN_CHUNK), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity, order_flag, order_gen, order_force);
+        if (lds && np >= BIN_LARGE_BATCH) hipExtLaunchKernelGGL((scatter_kernel<16>), dim3((np + BIN_THREADS * 16 - 1) / (BIN_THREADS * 16)), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity, order_flag, order_gen, order_force);
+        else if (lds) hipExtLaunchKernelGGL((scatter_kernel<8>), dim3((np + BIN_THREADS * 8 - 1) / (BIN_THREADS * 8)), dim3(BIN_THREADS), (size_t)ntiles * sizeof(unsigned), s, nullptr, done, 0, hdr, np, twl, tiles_x, ntiles, (const unsigned *)offset, cursor, list, capacity, order_flag, order_gen, order_force);
         else hipExtLaunchKernelGGL(scatter_direct_kernel, dim3((np + 255) / 256), dim3(256), 0, s, nullptr, done, 0, hdr, np, twl, tiles_x, (const unsigned *)offset, cursor, list, capacity);
     }
 }
