@@ -2987,9 +2987,7 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
     __syncthreads();
 
     __builtin_amdgcn_s_setprio(0);
-    // ---- colour pass + tile out.  Pixels are taken four at a time per lane so that the
-    // four winners' headers and edge coordinates are fetched together (one memory round
-    // trip for the group, a second one for the winning edges' values).
+    // ---- colour pass + tile out: every pixel's colour from its winner (GraphicsPoly.cpp:372, 486), the frame written once.
     unsigned long long qrows = 0;
     constexpr int CG = 4;
     if (NA >= 4) {
@@ -3100,29 +3098,20 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
             }
         }
     } else
+    // flat fill: a pixel's colour is its winner's, already lit (four winners' headers in flight per lane)
     for (int p0 = t; p0 < TW * TH; p0 += RASTER_THREADS * CG) {
         long long kk[CG];
         int4 hh[CG];
-        int2 xy[CG][3];
 #pragma unroll
         for (int g = 0; g < CG; g++) {
             const int p = p0 + g * RASTER_THREADS;
             kk[g] = p < TW * TH ? keys[(p / TW) * KW + p % TW] : 0ll;
             hh[g] = zero4;
-#pragma unroll
-            for (int e = 0; e < 3; e++) xy[g][e] = make_int2(0, 0);
         }
 #pragma unroll
         for (int g = 0; g < CG; g++) {
             const unsigned id = (unsigned)kk[g];
-            if (id != 0u) {
-                const int poly = (int)(id - 1u);
-                hh[g] = *record_header(a.edges, ESZ / 4, poly);
-                if (NA > 1) {
-#pragma unroll
-                    for (int e = 0; e < 3; e++) xy[g][e] = *(const int2 *)edge_piece(a.edges, a.np, ESZ / 4, e, 0, poly);
-                }
-            }
+            if (id != 0u) hh[g] = *record_header(a.edges, ESZ / 4, (int)(id - 1u));
         }
 #pragma unroll
         for (int g = 0; g < CG; g++) {
@@ -3131,29 +3120,13 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
             const int lx = p % TW, ly = p / TW, gx = tx0 + lx, gy = ty0 + ly;
             if (gx >= a.W || gy >= a.H) continue;
             const long long k = kk[g];
-            const unsigned id = (unsigned)k;
             const size_t gi = (size_t)gy * a.W + gx;
-            if (id == 0u) {
+            if ((unsigned)k == 0u) {
                 if (a.clear_pending) { a.zbuf[gi] = INT_MAX; a.cbuf[gi] = a.clear_colour; }
                 continue;
             }
-            const int poly = (int)(id - 1u);
-            const int4 h = hh[g];
-            const int ne = h.w & 0xff, kind = (h.w >> 8) & 0xff;
-            int c = h.z;
-            if (NA > 1 && kind != KIND_FLAT) {
-                int S[NA], E[NA], I[NA], beg = 0, end = 0;
-                row_ends<NA>(a.edges, a.np, poly, ne, gy, beg, end, S, E, xy[g], rlut);
-                int span = end - beg;
-                if (span == 0) span = 1;
-                const double2 rs = rcp_pair(rlut, span);
-#pragma unroll
-                for (int q = 0; q < NA; q++) I[q] = tdivp(wsub(E[q], S[q]), rs);
-                if (NA == 6 && kind >= KIND_TEX_LIN && ((I[1 % NA] | I[2 % NA] | I[3 % NA]) != 0)) qrows++;
-                c = pixel_colour<NA>(a, h, poly, gx, gy, beg, end, S, I, gx - beg);
-            }
             a.zbuf[gi] = (int)(k >> 32);
-            a.cbuf[gi] = c;
+            a.cbuf[gi] = hh[g].z;
         }
     }
 
