@@ -4,7 +4,9 @@ design notes): 100M Gouraud triangles at 16384 x 16384, log_focus 13, vertex off
   a. as a whole frame,
   b. in the eight row bands of an 8-GPU sort-first split, every band setting up the whole stream
      (what each of eight GPUs would do with replicated input), one band after the other,
-  c. the same with the polygons routed to their bands first (lt_polygon_rows_dev + lists by band).
+  c. the same with the polygons routed to their bands first (lt_polygon_rows_dev + lists by band),
+  d. (--table-objects K, in place of b and c) the whole frame with the objects joined K at a time into tables of
+     objects, one GPU batch per table (lt_submit_objects_dev): what the host mirror makes of consecutive calls.
 
 The 100M triangles are ten objects of 10M (gen_c2 with seeds 0xC0FFEE05 + k), submitted in turn: the frame of ten
 M_render_polygon_object-like calls.  Checks: the bands' frame equals the whole frame (digests), the bands' fragment
@@ -32,6 +34,7 @@ def main():
     ap.add_argument("--tris-per-object", type=int, default=10_000_000)
     ap.add_argument("--frames", type=int, default=3)
     ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--table-objects", type=int, default=0, help="objects per table for step d (0: steps b and c instead)")
     args = ap.parse_args()
     import torch
     from raytracing_amd import bands as B, gpu as G, scenes as S
@@ -75,6 +78,52 @@ def main():
                           "drawn_pixels": int((z != 2**31 - 1).sum())}
     print(json.dumps(out["whole_frame"]), flush=True)
     del c, z
+    if args.table_objects > 0:
+        # d. tables of objects: the arrays laid end to end, a matrix and a vertex range per object
+        K = args.table_objects
+        tables = []
+        for a0 in range(0, len(objs), K):
+            grp = objs[a0:a0 + K]
+            tab = np.zeros((len(grp), 16), np.int32)
+            polys, vbase, pvbase = [], 0, 0
+            for i, (v, po, pv) in enumerate(grp):
+                tab[i, :12] = np.asarray(matrix, np.int32).reshape(12)
+                tab[i, 12], tab[i, 13] = vbase, v.shape[0]
+                q = po.clone()
+                q[:, 3] += pvbase
+                polys.append(q)
+                vbase += v.shape[0]
+                pvbase += pv.shape[0]
+            owner = torch.cat([torch.full((po.shape[0],), i, dtype=torch.int32, device=dev) for i, (_, po, _) in enumerate(grp)])
+            tables.append((torch.from_numpy(tab).to(dev), owner, torch.cat([g[0] for g in grp]), torch.cat(polys), torch.cat([g[2] for g in grp])))
+            del polys
+        objs.clear()
+        torch.cuda.empty_cache()
+        ctx.set_list_capacity(int(tables[0][3].shape[0]) * 4)
+
+        def draw_tables():
+            ctx.clear(0)
+            for (tab, owner, v, po, pv) in tables:
+                ctx.submit_objects_dev(tab, owner, v, po, pv, rt, lf, max_edges=3)
+
+        draw_tables(); ctx.flush()
+        ctx.reset_counters()
+        t0 = time.perf_counter()
+        for _ in range(args.frames):
+            draw_tables()
+        ctx.flush()
+        dt = (time.perf_counter() - t0) / args.frames
+        n = ctx.counters()
+        c, z = ctx.readback()
+        got = (S.frame_digest(c), S.frame_digest(z))
+        out["tables"] = {"objects_per_table": K, "ms_per_frame": round(dt * 1e3, 3), "mtris_per_s": round(n_total / dt / 1e6, 1),
+                         "mfragments_per_s": round(n["fragments"] // args.frames / dt / 1e6, 1),
+                         "fragments_equal_whole_frame": n["fragments"] // args.frames == frags_whole,
+                         "frame_equals_whole_frame": got == whole}
+        print(json.dumps(out["tables"]), flush=True)
+        ctx.close()
+        print(json.dumps(out), flush=True)
+        return
     # b. eight bands, replicated input
     bands = list(B.all_bands(8, H))
     ctx.reset_counters()
