@@ -43,13 +43,25 @@ int q_focus = 0, q_force = 0;
 std::vector<int32_t> q_tuples, q_desc;               // Q_SCREEN
 std::vector<int32_t> q_prp;                          // Q_SCREEN with the perspective mapper: 12 words a polygon
 constexpr int LT_TEXTURED_PRP = 9;                   // queue type of G_prp_textured_polygon (no C-ABI render type)
-std::vector<int32_t> q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
+// (vectors whose resize() leaves new elements uninitialised: the queues of a frame of many objects grow by
+// hundreds of megabytes that are written straight afterwards)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+using IVec = std::vector<int32_t, NoInitAlloc<int32_t>>;
+IVec q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
 std::vector<int32_t> q_lines;                        // Q_LINES: {x1 y1 z1 x2 y2 z2 lit-colour 0}
 // Q_OBJECTS: consecutive M_render_polygon_object calls of one render type, laid end to end in
 // q_verts / q_polys / q_aux / q_pv, with one lt_object per call (its matrix and vertex range)
 // and each polygon's object: one GPU batch for all of them (lt_submit_objects)
 std::vector<lt_object> q_objects;
-std::vector<int32_t> q_polyobj;
+IVec q_polyobj;
 int q_max_edges = 0;
 // Textures are the caller's memory, read by the reference at draw time (GraphicsPoly.cpp:486).
 // Here a texel array is uploaded once and known by its address; the first use of an address
@@ -178,8 +190,7 @@ void open_queue(QKind kind, int type)
     g_host_frame_current = false;
 }
 
-void flatten_polygon(const M_polygon *p, int vertex_base, std::vector<int32_t> &polys, std::vector<int32_t> &aux,
-                     std::vector<int32_t> &pv)
+void flatten_polygon(const M_polygon *p, int vertex_base, IVec &polys, IVec &aux, IVec &pv)
 {
     int first = (int)(pv.size() / 6);
     int tex = -1;
@@ -1071,7 +1082,7 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
         // wireframes read the depth buffer without writing it and are drawn object by object
         run_queue();
         g_host_frame_current = false;
-        std::vector<int32_t> polys, aux, pv;
+        IVec polys, aux, pv;
         int me = 0;
         for (int i = 0; i < object->m_no_polygons; i++) {
             flatten_polygon(object->m_polygons[i], 0, polys, aux, pv);
@@ -1103,9 +1114,26 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
     const int index = (int)q_objects.size();
     q_objects.push_back(o);
     q_verts.insert(q_verts.end(), object->m_vertices, object->m_vertices + (size_t)object->m_no_vertices * T_LNG_VECTOR);
-    for (int i = 0; i < object->m_no_polygons; i++) {
-        flatten_polygon(object->m_polygons[i], 0, q_polys, q_aux, q_pv);
-        q_polyobj.push_back(index);
-        if (object->m_polygons[i]->m_no_edges > q_max_edges) q_max_edges = object->m_polygons[i]->m_no_edges;
+    // the object's polygons in one go: the arrays grow once, and every polygon is two short rows and a copy of its
+    // vertex records (a world of thousands of small objects makes this loop the frame's host time)
+    const int n = object->m_no_polygons;
+    size_t nrec = 0;
+    for (int i = 0; i < n; i++) nrec += (size_t)object->m_polygons[i]->m_no_edges + 1;
+    const size_t p0 = q_polys.size(), a0 = q_aux.size(), v0 = q_pv.size(), o0 = q_polyobj.size();
+    q_polys.resize(p0 + (size_t)n * 4); q_aux.resize(a0 + (size_t)n * 4); q_pv.resize(v0 + nrec * 6); q_polyobj.resize(o0 + (size_t)n);
+    int32_t *pp = q_polys.data() + p0, *pa = q_aux.data() + a0, *pr = q_pv.data() + v0, *po = q_polyobj.data() + o0;
+    int first = (int)(v0 / 6);
+    for (int i = 0; i < n; i++) {
+        const M_polygon *p = object->m_polygons[i];
+        const int ne = p->m_no_edges;
+        pp[0] = p->m_colour;
+        pp[1] = p->m_texture ? texture_handle(p->m_texture->m_texture_bytes, p->m_texture->m_log_texture_size) : -1;
+        pp[2] = ne; pp[3] = first;
+        pa[0] = p->m_red; pa[1] = p->m_green; pa[2] = p->m_blue; pa[3] = (p->m_type & 0xff) | (p->m_log_texture_space_size << 8);
+        memcpy(pr, p->m_vertices, (size_t)(ne + 1) * M_LNG_POLYGON_VERTEX * sizeof(int32_t));
+        pp += 4; pa += 4; pr += (size_t)(ne + 1) * M_LNG_POLYGON_VERTEX;
+        first += ne + 1;
+        po[i] = index;
+        if (ne > q_max_edges) q_max_edges = ne;
     }
 }

@@ -5,6 +5,7 @@
 #include "lt_data.h"
 #include <stddef.h>
 #include <stdlib.h>
+#include <time.h>
 #include <vector>
 
 static M_texture g_texs[64];        // textures registered through lte_set_texture
@@ -215,3 +216,43 @@ void lte_g_prp_polygon(int *tuples, int length, int *O, int *u, int *v, int tex,
 void lte_track_clipper_stores(int on) { HW_track_clipper_stores(on); }
 
 }  // extern "C"
+
+// Timing of a frame drawn as a reference-style program draws it: `frames` times G_clear and then
+// M_render_polygon_object for every object of `per_object` polygons in turn (per_object >= np: the whole
+// soup as one object), HW_flush at the end.  The M_polygon / M_polygon_object structures are built once,
+// as such a program would hold them.  The soup's vertices lie three a triangle in polygon order;
+// `pv_rel` holds the vertex records with indices counted from their object's first vertex.
+// Returns milliseconds per frame (host clock around the whole loop, the final flush included).
+extern "C" double lte_time_objects(int *verts, int nv, const int *polys, const int *aux, int *pv_rel, int np, int per_object,
+                                   int type, int log_focus, int frames)
+{
+    std::vector<M_polygon> store(np);
+    std::vector<M_polygon *> ptrs(np);
+    for (int i = 0; i < np; i++) { fill(&store[i], g_texs, polys, aux, pv_rel, i); ptrs[i] = &store[i]; }
+    if (per_object > np) per_object = np;
+    std::vector<M_polygon_object> objs;
+    for (int a = 0; a < np; a += per_object) {
+        const int n = a + per_object <= np ? per_object : np - a;
+        M_polygon_object o;
+        o.m_type = M_POLYGON_OBJECT; o.m_order = nullptr;
+        o.m_no_polygons = n; o.m_polygons = ptrs.data() + a;
+        o.m_no_vertices = per_object >= np ? nv : 3 * n; o.m_vertices = verts + (per_object >= np ? 0 : (size_t)3 * a * 4);
+        o.m_no_normals = 0; o.m_normals = nullptr;
+        objs.push_back(o);
+    }
+    M_init_rendering(type);
+    M_set_camera(0, 0, 0, 0, 0, 0, log_focus);
+    struct timespec t0, t1;
+    // one untimed frame first (allocations, code loading)
+    G_clear(0, 255, 255, 255);
+    for (M_polygon_object &o : objs) M_render_polygon_object(&o, 0, 0, 0, 0, 0, 0);
+    HW_flush();
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int f = 0; f < frames; f++) {
+        G_clear(0, 255, 255, 255);
+        for (M_polygon_object &o : objs) M_render_polygon_object(&o, 0, 0, 0, 0, 0, 0);
+    }
+    HW_flush();
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return ((t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6) / (frames > 0 ? frames : 1);
+}
