@@ -38,9 +38,10 @@ def main():
     rel = pv.copy()
     obj_of_record = np.repeat(np.arange(args.tris) // per, 4)          # four records a triangle
     rel[:, 0] -= (obj_of_record * 3 * per).astype(np.int32)
-    ms = L.lte_time_objects(p(verts), verts.shape[0], p(polys), None, p(rel), args.tris, per, sc.render_type, sc.log_focus, args.frames)
+    calls = C.c_double(0)
+    ms = L.lte_time_objects(p(verts), verts.shape[0], p(polys), None, p(rel), args.tris, per, sc.render_type, sc.log_focus, args.frames, C.byref(calls))
     c_mirror = np.ctypeslib.as_array(L.lte_cbuf(), shape=(sc.height, sc.width)).copy()
-    out["mirror_objects_of_%d" % per] = {"ms_per_frame": round(ms, 3), "calls_per_frame": (args.tris + per - 1) // per}
+    out["mirror_objects_of_%d" % per] = {"ms_per_frame": round(ms, 3), "ms_inside_the_calls": round(calls.value, 3), "calls_per_frame": (args.tris + per - 1) // per}
     # the same triangles as one object through the C-ABI (M_render_polygon_object itself refuses more than 256 polygons
     # a call, EngPoly.cpp:507-508): host arrays too
     import time
