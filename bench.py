@@ -528,7 +528,10 @@ def main():
     ap.add_argument("--sample-every", type=int, default=0,
                     help="time the slowest kernel inside the region on every Nth frame (0: every 4th, or every frame of a short region)")
     ap.add_argument("--hw-queues", type=int, default=8,
-                    help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4; the library keeps four streams busy)")
+                    help="GPU_MAX_HW_QUEUES for this process (HIP's default is 4; the library keeps four streams busy); "
+                         "0 leaves the environment as it is (the library then sets 8 if the variable is unset)")
+    ap.add_argument("--hip-first", action="store_true",
+                    help="start HIP before the library is loaded (with --hw-queues 0 and the variable unset: the process keeps HIP's four queues)")
     args = ap.parse_args()
     if args.headline_only:
         args.no_alone_pass = args.no_large_class = args.no_cpu = args.no_side_lines = True
@@ -538,9 +541,10 @@ def main():
     # HIP gives a process GPU_MAX_HW_QUEUES hardware queues (4 unless set) and lets streams share
     # them; the library keeps two frames in flight on four streams of its own beside the caller's,
     # and two of them sharing one queue run one after the other.  Read when HIP starts: set first.
-    if not 1 <= args.hw_queues <= 32:
-        raise SystemExit("--hw-queues outside 1..32")
-    os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
+    if not 0 <= args.hw_queues <= 32:
+        raise SystemExit("--hw-queues outside 0..32")
+    if args.hw_queues:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hw_queues)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -561,6 +565,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.hip_first:
+        torch.cuda.init()
     from raytracing_amd import bands as B, gpu as G
 
     torch.cuda.set_device(local_rank)

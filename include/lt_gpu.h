@@ -148,6 +148,9 @@ int lt_framebuffer(lt_ctx *ctx, int32_t **d_colour, int32_t **d_depth);
  * addresses.  Default: on if the environment variable GPU_MAX_HW_QUEUES (HIP's number of hardware
  * queues per process, read when HIP starts; 4 when unset) is 8 or more, else off -- the second
  * frame needs streams with hardware queues of their own to pay; 1 / 0 here override that.
+ * When this library is loaded into a process that has not set the variable and in which HIP has
+ * not started yet (no HIP call so far), it sets the variable to 8 itself; a value already set
+ * stays, and a process whose HIP runtime is already running keeps the queues it has.
  * No counterpart in the reference. */
 int lt_set_frame_overlap(lt_ctx *ctx, int on);
 /* Draw into caller-owned device arrays int32[height][width] (both, or both NULL to go

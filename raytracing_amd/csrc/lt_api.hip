@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,6 +28,26 @@ struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
 };
+
+// HIP reads GPU_MAX_HW_QUEUES (hardware queues per process, four if unset) when its runtime starts,
+// which is at the process's first HIP call, not when its library is loaded.  A program that loads
+// this library before that call and has not set the variable gets eight, the number the library's
+// four streams beside the caller's need to run side by side; a value already in the environment
+// stays.  Once the runtime has started the variable is past changing: the runtime holds the
+// kernel driver's device node open from then on, and a process that already has it is left alone.
+__attribute__((constructor)) void default_hw_queues()
+{
+    if (getenv("GPU_MAX_HW_QUEUES")) return;
+    for (int fd = 0; fd < 1024; fd++) {
+        char link[32], target[64];
+        snprintf(link, sizeof link, "/proc/self/fd/%d", fd);
+        const ssize_t n = readlink(link, target, sizeof target - 1);
+        if (n <= 0) continue;
+        target[n] = 0;
+        if (!strcmp(target, "/dev/kfd")) return;
+    }
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+}
 
 }  // namespace
 

@@ -8,6 +8,12 @@ import numpy as np
 from . import _lib
 from .scenes import IDENTITY, Scene
 
+# Loaded with this module when it has been built, not at the first Context: the library prepares
+# the process's environment for HIP, which only counts before the first HIP call.  A missing
+# library is reported by the first Context.
+if _lib.os.path.exists(_lib.SO_PATH):
+    _lib.lib()
+
 LT_FLAT, LT_SHADED, LT_TEXTURED = 2, 4, 8
 DIM = {LT_FLAT: 3, LT_SHADED: 6, LT_TEXTURED: 8}
 
