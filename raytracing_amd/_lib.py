@@ -19,6 +19,7 @@ EXPORTS = [
     "lt_set_clip_window", "lt_shade_points_dev", "lt_shade_points",
     "lt_set_tile_width", "lt_submit_object_dev_noalloc", "lt_submit_screen_polys_prp", "lt_polygon_rows_dev",
     "lt_submit_objects", "lt_submit_objects_dev", "lt_set_tile_waves",
+    "lt_set_copy_threads", "lt_host_alloc", "lt_host_free",
 ]
 
 
@@ -50,6 +51,9 @@ def lib():
     L.lt_last_error.argtypes = [vp]
     L.lt_last_error.restype = C.c_char_p
     L.lt_set_stream.argtypes = [vp, vp]
+    L.lt_set_copy_threads.argtypes = [vp, i32]
+    L.lt_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.lt_host_free.argtypes = [vp]
     L.lt_set_list_capacity.argtypes = [vp, u64]
     L.lt_clear.argtypes = [vp, C.c_int32]
     L.lt_flush.argtypes = [vp]

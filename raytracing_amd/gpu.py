@@ -41,6 +41,29 @@ def _dp(t):
     return C.c_void_p(t.data_ptr())
 
 
+def host_alloc(shape):
+    """a numpy int32 array in pinned host memory (lt_host_alloc); free it with host_free(array)"""
+    L = _lib.lib()
+    n = int(np.prod(shape))
+    p = C.c_void_p()
+    rc = L.lt_host_alloc(n * 4, C.byref(p))
+    if rc:
+        raise LtError(rc, L.lt_last_error(None).decode())
+    a = np.ctypeslib.as_array((C.c_int32 * n).from_address(p.value)).reshape(shape)
+    _pinned[a.ctypes.data] = p
+    return a
+
+
+def host_free(a):
+    p = _pinned.pop(a.ctypes.data)
+    rc = _lib.lib().lt_host_free(p)
+    if rc:
+        raise LtError(rc, _lib.lib().lt_last_error(None).decode())
+
+
+_pinned = {}
+
+
 class Context:
     """One framebuffer on one GPU."""
 
@@ -188,6 +211,10 @@ class Context:
     def set_tile_waves(self, waves):
         """waves on a 64-pixel tile of the fill: 4, 8, or 0 = chosen by the library"""
         self._chk(self.L.lt_set_tile_waves(self.h_ctx, waves))
+
+    def set_copy_threads(self, threads):
+        """host threads that move large host arrays through the pinned ring (1..16)"""
+        self._chk(self.L.lt_set_copy_threads(self.h_ctx, threads))
 
     def set_clip_window(self, minx, miny, maxx, maxy):
         """C_init_clipping for the batches submitted next"""

@@ -55,13 +55,48 @@ struct NoInitAlloc : std::allocator<T> {
     }
 };
 using IVec = std::vector<int32_t, NoInitAlloc<int32_t>>;
-IVec q_verts, q_polys, q_aux, q_pv;  // Q_VIEW (vertices already in view space)
+// The queues of view-space polygons and of whole objects are written anew every frame and handed to the
+// library as host arrays.  Their larger blocks are pinned memory (lt_host_alloc): the copy engine reads
+// pinned arrays as they are, at the rate of the link, where arrays of the C heap are first copied by host
+// threads whose reads leave the lines in other cores' caches and make the next frame's writes slow.  Blocks
+// that the library cannot pin (no GPU yet, or more than 1 GB at once) come from the C heap.  The queues live
+// until the process ends and are never destroyed: at exit HIP may be gone before a destructor here runs.
+std::map<void *, bool> &pinned_blocks()
+{
+    static std::map<void *, bool> *m = new std::map<void *, bool>;
+    return *m;
+}
+template <class T>
+struct QueueAlloc : NoInitAlloc<T> {
+    template <class U> struct rebind { using other = QueueAlloc<U>; };
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        void *p = nullptr;
+        if (bytes >= ((size_t)64 << 10) && bytes <= ((size_t)1 << 30) && lt_host_alloc(bytes, &p) == LT_OK) {
+            pinned_blocks()[p] = true;
+            return (T *)p;
+        }
+        p = malloc(bytes);
+        if (!p) throw std::bad_alloc();
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t)
+    {
+        auto it = pinned_blocks().find(p);
+        if (it == pinned_blocks().end()) { free(p); return; }
+        pinned_blocks().erase(it);
+        (void)lt_host_free(p);
+    }
+};
+using QVec = std::vector<int32_t, QueueAlloc<int32_t>>;
+QVec &q_verts = *new QVec, &q_polys = *new QVec, &q_aux = *new QVec, &q_pv = *new QVec;  // Q_VIEW (vertices already in view space)
 std::vector<int32_t> q_lines;                        // Q_LINES: {x1 y1 z1 x2 y2 z2 lit-colour 0}
 // Q_OBJECTS: consecutive M_render_polygon_object calls of one render type, laid end to end in
 // q_verts / q_polys / q_aux / q_pv, with one lt_object per call (its matrix and vertex range)
 // and each polygon's object: one GPU batch for all of them (lt_submit_objects)
 std::vector<lt_object> q_objects;
-IVec q_polyobj;
+QVec &q_polyobj = *new QVec;
 int q_max_edges = 0;
 // Textures are the caller's memory, read by the reference at draw time (GraphicsPoly.cpp:486).
 // Here a texel array is uploaded once and known by its address; the first use of an address
@@ -190,7 +225,8 @@ void open_queue(QKind kind, int type)
     g_host_frame_current = false;
 }
 
-void flatten_polygon(const M_polygon *p, int vertex_base, IVec &polys, IVec &aux, IVec &pv)
+template <class V>
+void flatten_polygon(const M_polygon *p, int vertex_base, V &polys, V &aux, V &pv)
 {
     int first = (int)(pv.size() / 6);
     int tex = -1;
