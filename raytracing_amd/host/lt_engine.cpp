@@ -301,8 +301,16 @@ void G_init_graphics(void)
         HW_error(buf);
     }
     G_c_buffer_size = (long)g_w * g_h;
-    G_c_buffer = (HW_pixel *)malloc(sizeof(HW_pixel) * G_c_buffer_size);
-    G_z_buffer = (int *)malloc(sizeof(int) * G_c_buffer_size);
+    // the host copy of the frame in pinned memory where the library can provide it: HW_flush then costs the
+    // link's time for 8 bytes a pixel and no host copy (the reference's arrays are the C heap's,
+    // GraphicsBase.cpp:76, 86; neither is ever freed)
+    auto frame_array = [](size_t bytes) {
+        void *p = nullptr;
+        if (lt_host_alloc(bytes, &p) != LT_OK) p = malloc(bytes);
+        return p;
+    };
+    G_c_buffer = (HW_pixel *)frame_array(sizeof(HW_pixel) * G_c_buffer_size);
+    G_z_buffer = (int *)frame_array(sizeof(int) * G_c_buffer_size);
     if (!G_c_buffer || !G_z_buffer) HW_error((char *)"(Graphics) Not enough memory.\n");
     C_init_clipping(0, 0, g_w - 1, g_h - 1);
 }
