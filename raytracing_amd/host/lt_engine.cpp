@@ -7,9 +7,11 @@
 #include <limits.h>
 #include <math.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <emmintrin.h>
 #include <map>
 #include <utility>
 #include <vector>
@@ -186,6 +188,7 @@ int texture_handle(HW_pixel *texels, int log_size, bool may_flush = false)
 void run_queue()
 {
     bool submitted = true;
+    _mm_sfence();                                    // the queues' streaming stores, before anyone else reads the arrays
     if (q_kind == Q_SCREEN && !q_desc.empty() && q_type == LT_TEXTURED_PRP) {
         chk(lt_submit_screen_polys_prp(g_ctx, q_tuples.data(), (int)(q_tuples.size() / 8), q_desc.data(), q_prp.data(),
                                        (int)(q_desc.size() / 4), q_focus, q_max_edges));
@@ -223,6 +226,18 @@ void open_queue(QKind kind, int type)
         run_queue();
     q_kind = kind; q_type = type; q_focus = M_camera_log_focus; q_force = M_force_linear_tmapping;
     g_host_frame_current = false;
+}
+
+// The object queues are written once and next read by the copy engine, not by this thread: 16-byte
+// stores that go past the caches (no read of the line that is about to be overwritten, and the queue does
+// not evict the program's own data).  run_queue fences them before the arrays are handed over.
+inline void stream_ints(int32_t *dst, const int32_t *src, size_t ints)
+{
+    if ((((uintptr_t)dst) & 15) == 0 && (ints & 3) == 0) {
+        for (size_t i = 0; i < ints; i += 4) _mm_stream_si128((__m128i *)(dst + i), _mm_loadu_si128((const __m128i *)(src + i)));
+    } else {
+        memcpy(dst, src, ints * sizeof(int32_t));
+    }
 }
 
 template <class V>
@@ -1157,7 +1172,11 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
     o.vert_count = object->m_no_vertices;
     const int index = (int)q_objects.size();
     q_objects.push_back(o);
-    q_verts.insert(q_verts.end(), object->m_vertices, object->m_vertices + (size_t)object->m_no_vertices * T_LNG_VECTOR);
+    {
+        const size_t at = q_verts.size(), more = (size_t)object->m_no_vertices * T_LNG_VECTOR;
+        q_verts.resize(at + more);
+        stream_ints(q_verts.data() + at, object->m_vertices, more);
+    }
     // the object's polygons in one go: the arrays grow once, and every polygon is two short rows and a copy of its
     // vertex records (a world of thousands of small objects makes this loop the frame's host time)
     const int n = object->m_no_polygons;
@@ -1170,11 +1189,12 @@ void M_render_polygon_object(struct M_polygon_object *object, int x, int y, int 
     for (int i = 0; i < n; i++) {
         const M_polygon *p = object->m_polygons[i];
         const int ne = p->m_no_edges;
-        pp[0] = p->m_colour;
-        pp[1] = p->m_texture ? texture_handle(p->m_texture->m_texture_bytes, p->m_texture->m_log_texture_size) : -1;
-        pp[2] = ne; pp[3] = first;
-        pa[0] = p->m_red; pa[1] = p->m_green; pa[2] = p->m_blue; pa[3] = (p->m_type & 0xff) | (p->m_log_texture_space_size << 8);
-        memcpy(pr, p->m_vertices, (size_t)(ne + 1) * M_LNG_POLYGON_VERTEX * sizeof(int32_t));
+        const int32_t hd[4] = {p->m_colour, p->m_texture ? texture_handle(p->m_texture->m_texture_bytes, p->m_texture->m_log_texture_size) : -1,
+                               ne, first};
+        const int32_t ax[4] = {p->m_red, p->m_green, p->m_blue, (p->m_type & 0xff) | (p->m_log_texture_space_size << 8)};
+        stream_ints(pp, hd, 4);
+        stream_ints(pa, ax, 4);
+        stream_ints(pr, p->m_vertices, (size_t)(ne + 1) * M_LNG_POLYGON_VERTEX);
         pp += 4; pa += 4; pr += (size_t)(ne + 1) * M_LNG_POLYGON_VERTEX;
         first += ne + 1;
         po[i] = index;
