@@ -16,12 +16,14 @@ constexpr int TH = 32;            // tile height (rows)
 constexpr int TW_NARROW = 64, TW_WIDE = 128;
 constexpr int SETUP_THREADS = 128;
 
-// Per-polygon header written by the setup kernel (16 bytes).
+// Per-polygon header written by the setup kernels at the front of the polygon's record (16 bytes):
 //   yy    = miny | maxy<<16   rows [miny, maxy) are filled (GraphicsPoly.cpp:329)
 //   xx    = minx | maxx<<16   column range of the clipped polygon (for binning)
 //   colour: LT_FLAT: lit colour; LT_SHADED: base colour; LT_TEXTURED: base colour
 //   meta  = n_edges | kind<<8 | tex<<16 ; n_edges == 0 marks "nothing to draw"
-struct PrimHdr { int yy, xx, colour, meta; };
+// The binning kernels (tiles, bands) read their own dense array of the first two words only,
+// 8 bytes a polygon: a polygon that is drawn has at least one row, so yy == 0 marks "nothing to draw" there.
+struct PrimHdr { int yy, xx; };
 
 // Edge record after the y clip of GI_scan (GraphicsPoly.cpp:136), in 16-byte pieces:
 //   {x1|y1<<16, x2|y2<<16, Zstart, Zinc, start[1..NA-1], inc[1..NA-1], padding}

@@ -798,7 +798,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
             for (int q = 1; q < ESZ / 4; q++)
                 R[4 + e * (ESZ / 4 - 1) + (q - 1)] = make_int4(rec[4 * q], rec[4 * q + 1], rec[4 * q + 2], rec[4 * q + 3]);
         }
-        ((int4 *)a.hdr)[slot] = R[0];
+        ((int2 *)a.hdr)[slot] = make_int2(R[0].x, R[0].y);
         if (a.tile_count) count_tiles(a, by0, by1, minx, maxx);
     }
     {
@@ -819,7 +819,7 @@ __global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArg
             }
         }
     }
-    if (lane >= count && base + lane < a.np) ((int4 *)a.hdr)[base + lane] = make_int4(0, 0, 0, 0);
+    if (lane >= count && base + lane < a.np) ((int2 *)a.hdr)[base + lane] = make_int2(0, 0);
     // queue the rest for the general kernel as {polygon, slot}: one atomic per wave,
     // spread over QUEUES sub-queues by workgroup index (thousands of waves adding to one
     // word would queue behind each other); sub-queue q holds at most `queue_cap` entries
@@ -894,7 +894,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
 {
     constexpr int NA = DIM - 2;
     constexpr int ESZ = edge_ints(NA);
-    PrimHdr hdr;
+    struct { int yy, xx, colour, meta; } hdr;
     hdr.yy = 0; hdr.xx = 0; hdr.colour = 0; hdr.meta = 0;
 
     const int4 pd = ((const int4 *)a.polys)[poly];
@@ -1202,7 +1202,7 @@ __device__ __forceinline__ void setup_one(const SetupArgs &a, const int poly, co
         hdr.colour = col;
         hdr.meta = ne | (kind << 8) | ((tex < 0 ? 0 : tex) << 16);
     }
-    ((int4 *)a.hdr)[slot] = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
+    ((int2 *)a.hdr)[slot] = make_int2(hdr.yy, hdr.xx);
     *record_header(a.edges, ESZ / 4, slot) = make_int4(hdr.yy, hdr.xx, hdr.colour, hdr.meta);
     if (a.tile_count && draw) count_tiles(a, miny, maxy, minx, maxx);
     if (DIM == 8 && a.detect_order) {
@@ -1303,9 +1303,9 @@ template <> __global__ void __launch_bounds__(SETUP_THREADS, 2) setup_queues_obj
 constexpr int BIN_THREADS = 512;
 constexpr int BIN_LARGE_BATCH = 1 << 22;
 
-__device__ __forceinline__ bool prim_tiles(const int4 h, int twl, int &tx0, int &tx1, int &ty0, int &ty1)
+__device__ __forceinline__ bool prim_tiles(const int2 h, int twl, int &tx0, int &tx1, int &ty0, int &ty1)
 {
-    if ((h.w & 0xff) == 0) return false;
+    if (h.x == 0) return false;          // no rows: nothing to draw
     int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff, minx = h.y & 0xffff, maxx = (h.y >> 16) & 0xffff;
     tx0 = minx >> twl; tx1 = maxx >> twl; ty0 = miny / TH; ty1 = (maxy - 1) / TH;
     return true;
@@ -1331,7 +1331,7 @@ __global__ void __launch_bounds__(BIN_THREADS) count_kernel(const PrimHdr *__res
         int poly = base + k * BIN_THREADS + threadIdx.x;
         if (poly < np) {
             int tx0, tx1, ty0, ty1;
-            if (prim_tiles(((const int4 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
+            if (prim_tiles(((const int2 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
                 for (int ty = ty0; ty <= ty1; ty++)
                     for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * tiles_x + tx], 1u);
         }
@@ -1355,11 +1355,11 @@ __global__ void __launch_bounds__(BIN_THREADS) scatter_kernel(const PrimHdr *__r
     __syncthreads();
     constexpr int BIN_CHUNK = BIN_THREADS * BIN_PER_THREAD;
     const int base = blockIdx.x * BIN_CHUNK;
-    int4 hs[BIN_PER_THREAD];
+    int2 hs[BIN_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < BIN_PER_THREAD; k++) {
         int poly = base + k * BIN_THREADS + threadIdx.x;
-        hs[k] = poly < np ? ((const int4 *)hdr)[poly] : make_int4(0, 0, 0, 0);
+        hs[k] = poly < np ? ((const int2 *)hdr)[poly] : make_int2(0, 0);
         int tx0, tx1, ty0, ty1;
         if (prim_tiles(hs[k], twl, tx0, tx1, ty0, ty1))
             for (int ty = ty0; ty <= ty1; ty++)
@@ -1391,7 +1391,7 @@ __global__ void __launch_bounds__(256) count_direct_kernel(const PrimHdr *__rest
     int poly = blockIdx.x * blockDim.x + threadIdx.x;
     if (poly >= np) return;
     int tx0, tx1, ty0, ty1;
-    if (prim_tiles(((const int4 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
+    if (prim_tiles(((const int2 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&count[ty * tiles_x + tx], 1u);
 }
@@ -1404,7 +1404,7 @@ __global__ void __launch_bounds__(256) scatter_direct_kernel(const PrimHdr *__re
     int poly = blockIdx.x * blockDim.x + threadIdx.x;
     if (poly >= np) return;
     int tx0, tx1, ty0, ty1;
-    if (prim_tiles(((const int4 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
+    if (prim_tiles(((const int2 *)hdr)[poly], twl, tx0, tx1, ty0, ty1))
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 int tile = ty * tiles_x + tx;
@@ -1957,7 +1957,11 @@ __global__ void __launch_bounds__(256) ordered_kernel(RasterArgs a, int R)
     for (int base = 0; base < a.np; base += 64) {
         const int mypoly = base + lane;
         int4 h = make_int4(0, 0, 0, 0);
-        if (mypoly < a.np) h = ((const int4 *)a.hdr)[mypoly];
+        if (mypoly < a.np) {
+            const int2 rc = ((const int2 *)a.hdr)[mypoly];
+            // the whole header (colour, edge count, kind, texture) is at the front of the polygon's record
+            if (rc.x != 0 && (rc.x & 0xffff) < y1 && ((rc.x >> 16) & 0xffff) > y0) h = *record_header(a.edges, edge_ints(NA) / 4, mypoly);
+        }
         const bool ov = (h.w & 0xff) != 0 && (h.x & 0xffff) < y1 && ((h.x >> 16) & 0xffff) > y0;
         unsigned long long mask = __ballot(ov);
         while (mask) {
@@ -2044,8 +2048,8 @@ __global__ void __launch_bounds__(BAND_THREADS) band_bin_kernel(BandArgs a, int 
         for (int k = 0; k < BAND_CHUNK / BAND_THREADS; k++) {
             const int idx = k * BAND_THREADS + t, slot = chunk * BAND_CHUNK + idx;
             if (slot < a.np) {
-                const int4 h = ((const int4 *)a.hdr)[slot];
-                if ((h.w & 0xff) != 0) {
+                const int2 h = ((const int2 *)a.hdr)[slot];
+                if (h.x != 0) {
                     const int miny = h.x & 0xffff, maxy = (h.x >> 16) & 0xffff;
                     const int b0 = miny / a.R, b1 = min((maxy - 1) / a.R, a.nb - 1);
                     for (int b = b0; b <= b1; b++) atomicOr(&band_bits[b * BAND_PITCH + (idx >> 5)], 1u << (idx & 31));
