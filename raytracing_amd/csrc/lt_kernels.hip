@@ -561,7 +561,7 @@ __device__ __forceinline__ const int4 *record_header(const int *edges, int npiec
 // screen-border contact, perspective-mapped textures) is appended to a queue for the
 // general kernel, which then runs only on those polygons with all its lanes busy.
 template <int DIM, bool MULTI>
-__global__ void __launch_bounds__(SETUP_FAST_THREADS) setup_fast_kernel(SetupArgs a)
+__global__ void __launch_bounds__(SETUP_FAST_THREADS) __attribute__((amdgpu_waves_per_eu(DIM <= 6 ? 5 : 4, DIM <= 6 ? 5 : 4))) setup_fast_kernel(SetupArgs a)
 {
     // The kernels of a batch's set-up chain run beside the fills of earlier batches, each waiting
     // for the one before it: their waves take the highest wave priority, so that a SIMD shared
@@ -2656,8 +2656,14 @@ constexpr unsigned HIZ_MIN_REFS = 1024;                   // tile list length fr
 // lasts as long as the workgroup of the longest list; with twice the waves on it, one million
 // triangles rotating at a distance fill in 107 instead of 162 us, while the evenly spread frame
 // takes 84 instead of 76 us that way).
+// The staging rows of the narrow tile's flat and Gouraud fills with four waves are dynamic LDS that the launch adds
+// (RASTER_STAGE_DYNAMIC bytes), not a static array: with all 40 KB static the compiler sees four workgroups a CU,
+// hence four waves a SIMD, and lets the kernel have 97 registers -- one more than five waves a SIMD can have.  A
+// SIMD's 512 registers are what the fill's waves and the set-up waves of the batch behind them share: at 96 each,
+// three of the fill and two of the fast set-up fit, at 97 and 98 (what both kernels took when left alone) four in all.
+constexpr unsigned RASTER_STAGE_DYNAMIC = 256 * 5 * 16;
 template <int NA, int TW, int NT>
-__global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
+__device__ __forceinline__ void raster_body(const RasterArgs &a)
 {
     constexpr int RASTER_THREADS = NT;
     // The class of polygons that lie wholly behind their tile (below) belongs to the wide tile, which the
@@ -2679,7 +2685,10 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
     __shared__ int zmax[TH * (TW / 8)];
     // per wave: 64 polygons x {edge 0, edge 1, edge 2 as {x1|y1<<16, edge_pack, Zstart, Zinc}, {hr of edges 0 and 1},
     // {hr of edge 2, polygon, edges | first row << 5 | row offset << 19}}
-    __shared__ int4 stage[RASTER_THREADS * 5];
+    constexpr bool DYN = TW == 64 && NA <= 4 && NT == 256;
+    __shared__ int4 stage_s[DYN ? 1 : RASTER_THREADS * 5];
+    extern __shared__ int4 stage_d[];
+    int4 *const stage = DYN ? stage_d : stage_s;
     __shared__ double2 rlut[64];
     // per wave: one bit per row of a round (64 polygons x TH rows), set at the last row of every polygon
     __shared__ unsigned long long marks[(RASTER_THREADS / 64) * (TH * 64 / 64)];
@@ -3147,6 +3156,13 @@ __global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a)
     }
 }
 
+template <int NA, int TW, int NT>
+__global__ void __launch_bounds__(NT) raster_kernel(RasterArgs a) { raster_body<NA, TW, NT>(a); }
+template <>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) raster_kernel<1, 64, 256>(RasterArgs a) { raster_body<1, 64, 256>(a); }
+template <>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) raster_kernel<4, 64, 256>(RasterArgs a) { raster_body<4, 64, 256>(a); }
+
 // G_clear (GraphicsBase.cpp:99-111) when a frame is read back with no draw after it.
 __global__ void __launch_bounds__(256) fill_kernel(int4 *__restrict__ c, int4 *__restrict__ z, size_t n4, int colour)
 {
@@ -3339,8 +3355,8 @@ void launch_raster(hipStream_t s, int na, int tile_w, const RasterArgs &a_in, hi
         else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 64, 512>), g, b, 0, s, start, stop, 0, a);
         else hipExtLaunchKernelGGL((raster_kernel<6, 64, 512>), g, b, 0, s, start, stop, 0, a);
     } else {
-        if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1, 64, 256>), g, b, extra_lds, s, start, stop, 0, a);
-        else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 64, 256>), g, b, extra_lds, s, start, stop, 0, a);
+        if (na == 1) hipExtLaunchKernelGGL((raster_kernel<1, 64, 256>), g, b, RASTER_STAGE_DYNAMIC + extra_lds, s, start, stop, 0, a);
+        else if (na == 4) hipExtLaunchKernelGGL((raster_kernel<4, 64, 256>), g, b, RASTER_STAGE_DYNAMIC + extra_lds, s, start, stop, 0, a);
         else hipExtLaunchKernelGGL((raster_kernel<6, 64, 256>), g, b, extra_lds, s, start, stop, 0, a);
     }
 }
