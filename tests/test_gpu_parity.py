@@ -220,3 +220,29 @@ def test_screen_polys_shaded(env):
     ctx.submit_screen_polys(G.LT_SHADED, polys)
     c, z = ctx.readback()
     assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+
+
+def test_polygons_of_the_first_rows_only(env):
+    """polygons whose rows are [0, 1) or [0, 2): the binning knows a polygon by its packed rows
+    (first | last << 16; zero means nothing to draw), which is smallest for these"""
+    P, G = env
+    W, H = 200, 150
+    L = 200 << 16
+    def tri(x0, x1, xm, ym, z, light):
+        t = np.array([[x0, 0, z, light, light, light], [x1, 0, z, light, light, light], [xm, ym, z, light, light, light],
+                      [x0, 0, z, light, light, light]], np.int32)
+        return (3, t, 0x00ffffff)
+    polys = [tri(0, 9, 4, 1, 500, L), tri(9, 0, 4, 1, 400, L // 2),       # both windings: rows [0, 1)
+             tri(20, 60, 40, 2, 300, L), tri(60, 20, 40, 2, 200, L // 2),   # rows [0, 2)
+             tri(190, 199, 195, 1, 100, L), tri(199, 190, 195, 1, 90, L // 2),
+             tri(100, 140, 120, 0, 80, L)]                                  # a single row of points: rows [0, 0), nothing
+    ctx = G.Context(W, H)
+    orc = P.Oracle(W, H)
+    orc.clear(0x112233, 255, 255, 255)
+    ctx.clear(P.cl_light(0x112233, 255, 255, 255))
+    for (e, t, col) in polys:
+        orc.g_polygon(4, t, colour=col)
+    ctx.submit_screen_polys(G.LT_SHADED, polys)
+    c, z = ctx.readback()
+    assert (z == orc.zbuf()).all() and (c == orc.cbuf()).all()
+    assert (z[0] != 2 ** 31 - 1).sum() > 40 and (z[2:] == 2 ** 31 - 1).all()
