@@ -456,7 +456,8 @@ def c3_side(torch, dist, dev, local_rank, tris, q2_tris, frames=24):
             ctx.submit_object_dev(d_verts, d_polys, d_pv, sc.render_type, sc.log_focus, d_polyaux=d_aux, matrix=sc.matrix,
                                   force_linear=sc.force_linear, max_edges=3)
 
-        dt, frags, n_ctr, err = side_frames(ctx, torch, dist, 1, dev, submit, nf, warm=2)
+        # (four warm-up frames: the context has four sets of work arrays, each allocated by the first batch that uses it)
+        dt, frags, n_ctr, err = side_frames(ctx, torch, dist, 1, dev, submit, nf, warm=4)
         out[name.replace("-", "_")] = {
             "workload": f"{name}: {sc.n_polys} textured triangles at {sc.width}x{sc.height}, log_focus {sc.log_focus}, "
                         + ("one light value per triangle" if name == "c3" else "differing vertex lights (draw-order fill)"),
