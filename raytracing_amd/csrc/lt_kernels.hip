@@ -560,6 +560,8 @@ __device__ __forceinline__ const int4 *record_header(const int *edges, int npiec
 // with p3 the stored closing tuple.  Everything else (other edge counts, near-plane or
 // screen-border contact, perspective-mapped textures) is appended to a queue for the
 // general kernel, which then runs only on those polygons with all its lanes busy.
+// (Flat and Gouraud: held to the 96 registers of five waves a SIMD -- it took 98 when left alone --, because its waves share a
+// SIMD's registers with three waves of a running fill: see raster_kernel.  The textured kernel would spill.)
 template <int DIM, bool MULTI>
 __global__ void __launch_bounds__(SETUP_FAST_THREADS) __attribute__((amdgpu_waves_per_eu(DIM <= 6 ? 5 : 4, DIM <= 6 ? 5 : 4))) setup_fast_kernel(SetupArgs a)
 {
